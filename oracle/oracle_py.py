@@ -1,0 +1,213 @@
+"""ctypes view of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product (pem-spgemm_amd/) never does.  PARITY UNPINNED: see oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in ("mm_read.c", "ref_tiled_cpu.c", "ref_serial_csr.c", "oracle.h")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_pi = C.POINTER(C.c_int)
+_pd = C.POINTER(C.c_double)
+
+
+class _Coo(C.Structure):
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("nnz", C.c_int64), ("I", _pi), ("J", _pi), ("V", _pd),
+                ("symmetric", C.c_int), ("field", C.c_int)]
+
+
+class _Tiled(C.Structure):
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("nnz", C.c_int), ("tile_rows", C.c_int), ("tile_cols", C.c_int),
+                ("ntiles", C.c_int),
+                ("tile_keys", C.POINTER(C.c_int64)), ("tile_nnz_ptr", _pi),
+                ("csr_rowptr", _pi), ("csr_col", _pi), ("csr_val", _pd),
+                ("masks", C.POINTER(C.c_uint16)), ("rowptr", C.POINTER(C.c_uint8)), ("rowcolidx", C.POINTER(C.c_uint8)),
+                ("vals", _pd), ("masks_t", C.POINTER(C.c_uint16)),
+                ("tile_rowptr", _pi), ("tile_colidx", _pi), ("tile_colptr", _pi), ("tile_rowidx", _pi),
+                ("tile_offsets", _pi)]
+
+
+class _Plan(C.Structure):
+    _fields_ = [("tr_lo", C.c_int), ("tr_hi", C.c_int), ("ntiles_c", C.c_int), ("npairs", C.c_int64), ("nnz_c", C.c_int64),
+                ("c_tile_rowptr", _pi), ("c_tile_rowidx", _pi), ("c_tile_colidx", _pi),
+                ("pairs_offset", _pi), ("pairs_a", _pi), ("pairs_b", _pi),
+                ("c_mask", C.POINTER(C.c_uint32)), ("c_tile_nnz_ptr", _pi),
+                ("c_rowptr", C.POINTER(C.c_uint8)), ("c_rowcolidx", C.POINTER(C.c_uint8)), ("c_vals", _pd)]
+
+
+class _Csr(C.Structure):
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("nnz", C.c_int64), ("rowptr", _pi), ("col", _pi), ("val", _pd)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.oracle_flop_count.restype = C.c_uint64
+    return _lib
+
+
+def _arr(ptr, n, dtype):
+    n = int(n)
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+def _ci(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def mm_read(path):
+    m = _Coo()
+    rc = lib().oracle_mm_read(path.encode(), C.byref(m))
+    if rc != 0:
+        raise RuntimeError(f"oracle_mm_read({path}) -> {rc}")
+    out = dict(rows=m.rows, cols=m.cols, nnz=int(m.nnz), I=_arr(m.I, m.nnz, np.int32), J=_arr(m.J, m.nnz, np.int32),
+               V=_arr(m.V, m.nnz, np.float64), symmetric=bool(m.symmetric), field=m.field)
+    lib().oracle_coo_free(C.byref(m))
+    return out
+
+
+class Tiled:
+    """a2-a7 arrays of one matrix (numpy copies) + the live C struct for the step functions."""
+
+    def __init__(self, rows, cols, I, J, V, transpose=False):
+        I, J, V = _ci(I), _ci(J), np.ascontiguousarray(V, dtype=np.float64)
+        self._s = _Tiled()
+        rc = lib().oracle_tiled_from_coo(int(rows), int(cols), int(len(I)), I.ctypes.data_as(_pi), J.ctypes.data_as(_pi),
+                                         V.ctypes.data_as(_pd), int(bool(transpose)), C.byref(self._s))
+        if rc != 0:
+            raise ValueError(f"oracle_tiled_from_coo -> {rc}")
+        s = self._s
+        T, nnz = s.ntiles, s.nnz
+        self.rows, self.cols, self.nnz = s.rows, s.cols, nnz
+        self.tile_rows, self.tile_cols, self.ntiles = s.tile_rows, s.tile_cols, T
+        self.tile_keys = _arr(s.tile_keys, T, np.int64)
+        self.tile_nnz_ptr = _arr(s.tile_nnz_ptr, T + 1, np.int32)
+        self.csr_rowptr = _arr(s.csr_rowptr, s.rows + 1, np.int32)
+        self.csr_col = _arr(s.csr_col, nnz, np.int32)
+        self.csr_val = _arr(s.csr_val, nnz, np.float64)
+        self.masks = _arr(s.masks, 16 * T, np.uint16)
+        self.rowptr = _arr(s.rowptr, 16 * T, np.uint8)
+        self.rowcolidx = _arr(s.rowcolidx, nnz, np.uint8)
+        self.vals = _arr(s.vals, nnz, np.float64)
+        self.masks_t = _arr(s.masks_t, 16 * T, np.uint16)
+        self.tile_rowptr = _arr(s.tile_rowptr, s.tile_rows + 1, np.int32)
+        self.tile_colidx = _arr(s.tile_colidx, T, np.int32)
+        self.tile_colptr = _arr(s.tile_colptr, s.tile_cols + 1, np.int32)
+        self.tile_rowidx = _arr(s.tile_rowidx, T, np.int32)
+        self.tile_offsets = _arr(s.tile_offsets, T, np.int32)
+
+    def __del__(self):
+        try:
+            lib().oracle_tiled_free(C.byref(self._s))
+        except Exception:
+            pass
+
+
+def flop_count(A, B):
+    return int(lib().oracle_flop_count(C.byref(A._s), C.byref(B._s)))
+
+
+class Plan:
+    """a9-a14 for C = A*B over A's tile rows [tr_lo, tr_hi)."""
+
+    def __init__(self, A, B, tr_lo=0, tr_hi=None):
+        self.A, self.B = A, B
+        tr_hi = A.tile_rows if tr_hi is None else tr_hi
+        self._s = _Plan()
+        L = lib()
+        for fn, args in ((L.oracle_spgemm_step1, (C.byref(A._s), C.byref(B._s), int(tr_lo), int(tr_hi), C.byref(self._s))),
+                         (L.oracle_spgemm_step2, (C.byref(A._s), C.byref(B._s), C.byref(self._s))),
+                         (L.oracle_spgemm_step3, (C.byref(A._s), C.byref(B._s), C.byref(self._s)))):
+            rc = fn(*args)
+            if rc != 0:
+                raise ValueError(f"oracle step -> {rc}")
+        s = self._s
+        TC, P, nz = s.ntiles_c, int(s.npairs), int(s.nnz_c)
+        self.tr_lo, self.tr_hi, self.ntiles_c, self.npairs, self.nnz_c = s.tr_lo, s.tr_hi, TC, P, nz
+        self.c_tile_rowptr = _arr(s.c_tile_rowptr, s.tr_hi - s.tr_lo + 1, np.int32)
+        self.c_tile_rowidx = _arr(s.c_tile_rowidx, TC, np.int32)
+        self.c_tile_colidx = _arr(s.c_tile_colidx, TC, np.int32)
+        self.pairs_offset = _arr(s.pairs_offset, TC + 1, np.int32)
+        self.pairs_a = _arr(s.pairs_a, P, np.int32)
+        self.pairs_b = _arr(s.pairs_b, P, np.int32)
+        self.c_mask = _arr(s.c_mask, 8 * TC, np.uint32)
+        self.c_tile_nnz_ptr = _arr(s.c_tile_nnz_ptr, TC + 1, np.int32)
+        self.c_rowptr = _arr(s.c_rowptr, 16 * TC, np.uint8)
+        self.c_rowcolidx = _arr(s.c_rowcolidx, nz, np.uint8)
+        self.c_vals = _arr(s.c_vals, nz, np.float64)
+
+    def export_coo(self):
+        nz = self.nnz_c
+        r, c, v = np.zeros(nz, np.int32), np.zeros(nz, np.int32), np.zeros(nz, np.float64)
+        lib().oracle_c_export_coo(C.byref(self._s), r.ctypes.data_as(_pi), c.ctypes.data_as(_pi), v.ctypes.data_as(_pd))
+        return r, c, v
+
+    def export_csr(self):
+        nz = self.nnz_c
+        r0, r1 = self.tr_lo * 16, min(self.tr_hi * 16, self.A.rows)
+        rp, c, v = np.zeros(r1 - r0 + 1, np.int32), np.zeros(nz, np.int32), np.zeros(nz, np.float64)
+        lib().oracle_c_export_csr(C.byref(self._s), int(self.A.rows), rp.ctypes.data_as(_pi), c.ctypes.data_as(_pi),
+                                  v.ctypes.data_as(_pd))
+        return rp, c, v
+
+    def __del__(self):
+        try:
+            lib().oracle_cplan_free(C.byref(self._s))
+        except Exception:
+            pass
+
+
+class Csr:
+    def __init__(self, rows=0, cols=0, I=None, J=None, V=None, transpose=False):
+        self._s = _Csr()
+        if I is not None:
+            I, J, V = _ci(I), _ci(J), np.ascontiguousarray(V, dtype=np.float64)
+            rc = lib().oracle_csr_from_coo(int(rows), int(cols), int(len(I)), I.ctypes.data_as(_pi), J.ctypes.data_as(_pi),
+                                           V.ctypes.data_as(_pd), int(bool(transpose)), C.byref(self._s))
+            if rc != 0:
+                raise ValueError(f"oracle_csr_from_coo -> {rc}")
+
+    rows = property(lambda self: self._s.rows)
+    cols = property(lambda self: self._s.cols)
+    nnz = property(lambda self: int(self._s.nnz))
+
+    def arrays(self):
+        s = self._s
+        return _arr(s.rowptr, s.rows + 1, np.int32), _arr(s.col, s.nnz, np.int32), _arr(s.val, s.nnz, np.float64)
+
+    def __del__(self):
+        try:
+            lib().oracle_csr_free(C.byref(self._s))
+        except Exception:
+            pass
+
+
+def csr_spgemm(A, B, threads=1):
+    out = Csr()
+    rc = lib().oracle_csr_spgemm(C.byref(A._s), C.byref(B._s), int(threads), C.byref(out._s))
+    if rc != 0:
+        raise ValueError(f"oracle_csr_spgemm -> {rc}")
+    return out
+
+
+def max_threads():
+    return int(lib().oracle_max_threads())

@@ -1,0 +1,585 @@
+// convert.hip -- rows a2-a8: COO/CSR -> 16x16 tiled CSR on the device, plus contexts.
+//
+// The reference sorts the tile keys, stable-sorts the (I,J,val) zip into CSR, then lets one
+// 256-thread block per tile binary-search the CSR (spgemm.cu:832-1062).  Here ONE radix sort
+// on the key (tileRow | tileCol | r | c) puts every nonzero directly at its final slot of the
+// tiled layout; tile boundaries, masks, intra-tile row pointers and the transposed masks
+// then fall out of the sorted keys with wave64 ballots / 16-lane scans.  The arrays produced
+// are bit-identical to the reference's (layouts in include/pem_spgemm.h).
+#include "pem_internal.h"
+#include <chrono>
+
+using namespace pem;
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+// a2 decide_which_tile (spgemm.cu:112-135), extended with the intra-tile (r,c) byte so the
+// sort order IS the tiled storage order.  transpose swaps the roles of I and J (:788-792).
+__global__ void conv_make_keys_kernel(const int *__restrict__ I, const int *__restrict__ J, size_t nnz, int rows, int cols,
+                                      int transpose, int bits_tc, uint64_t *__restrict__ keys, uint32_t *__restrict__ perm,
+                                      int *__restrict__ flags)
+{
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    int r = transpose ? J[e] : I[e];
+    int c = transpose ? I[e] : J[e];
+    if (r < 0 || r >= rows || c < 0 || c >= cols) {
+        flags[FLAG_RANGE] = 1;
+        r = 0;
+        c = 0;
+    }
+    keys[e] = ((uint64_t)(unsigned)(r >> 4) << (bits_tc + 8)) | ((uint64_t)(unsigned)(c >> 4) << 8) |
+              (uint64_t)(((r & 15) << 4) | (c & 15));
+    perm[e] = (uint32_t)e;
+}
+
+// CSR input: expand row pointers into the same keys (thread per row).
+__global__ void conv_csr_keys_kernel(const int *__restrict__ rowptr, const int *__restrict__ colidx, int rows, int cols,
+                                     int bits_tc, uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, int *__restrict__ flags)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+        int c = colidx[e];
+        if (c < 0 || c >= cols) {
+            flags[FLAG_RANGE] = 1;
+            c = 0;
+        }
+        keys[e] = ((uint64_t)(unsigned)(r >> 4) << (bits_tc + 8)) | ((uint64_t)(unsigned)(c >> 4) << 8) |
+                  (uint64_t)(((r & 15) << 4) | (c & 15));
+        perm[e] = (uint32_t)e;
+    }
+}
+
+// a3 (spgemm.cu:866-892 sort/unique/reduce_by_key): tile heads of the sorted key stream.
+__global__ void conv_heads_kernel(const uint64_t *__restrict__ keys, size_t nnz, int *__restrict__ head, int *__restrict__ flags)
+{
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    uint64_t k = keys[e];
+    int h = 1;
+    if (e > 0) {
+        uint64_t p = keys[e - 1];
+        h = (k >> 8) != (p >> 8);
+        if (k == p) flags[FLAG_DUP] = 1;
+    }
+    head[e] = h;
+}
+
+// a5 payload (spgemm.cu:195, 218-222): values + (r<<4|c) bytes in tile order; tile list +
+// perTileNnz offsets (spgemm.cu:873-877).  headx = exclusive scan of the head flags.
+__global__ void conv_fill_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm, const int *__restrict__ headx,
+                                 size_t nnz, const double *__restrict__ V, int bits_tc, double *__restrict__ vals,
+                                 uint8_t *__restrict__ rowcolidx, long long *__restrict__ tile_keys, int *__restrict__ tile_nnz_ptr)
+{
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    uint64_t k = keys[e];
+    vals[e] = V[perm[e]];
+    rowcolidx[e] = (uint8_t)(k & 0xFF);
+    int t = headx[e];
+    bool is_head = headx[e + 1] != t;
+    if (is_head) {
+        uint64_t tc = (k >> 8) & ((1ull << bits_tc) - 1ull);
+        uint64_t tr = k >> (8 + bits_tc);
+        tile_keys[t] = (long long)((tr << 32) | tc);
+        tile_nnz_ptr[t] = (int)e;
+    }
+    if (e == nnz - 1) tile_nnz_ptr[headx[nnz]] = (int)nnz;   // perTileNnz[T] = nnz
+}
+
+// a5 masks + intra-tile row pointers (spgemm.cu:196-209) and a6 transposed masks
+// (spgemm.cu:228-258).  16 lanes per tile, lane = tile row; one wave64 covers 4 tiles, so a
+// ballot returns the four 16-bit transposed rows at once.
+__global__ void __launch_bounds__(256) conv_tile_meta_kernel(const uint8_t *__restrict__ rowcolidx, const int *__restrict__ tile_nnz_ptr,
+                                                             long long ntiles, uint16_t *__restrict__ masks, uint8_t *__restrict__ rowptr,
+                                                             uint16_t *__restrict__ masks_t)
+{
+    long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int r = threadIdx.x & 15;
+    const int grp = (threadIdx.x & 63) >> 4;
+    const bool live = t < ntiles;
+    unsigned mask = 0;
+    if (live) {
+        int e0 = tile_nnz_ptr[t], e1 = tile_nnz_ptr[t + 1];
+        for (int e = e0; e < e1; ++e) {
+            unsigned rc = rowcolidx[e];
+            if ((int)(rc >> 4) == r) mask |= 1u << (rc & 15);
+        }
+    }
+    // exclusive scan of the row populations across the 16-lane group
+    int cnt = __popc(mask), inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        int v = __shfl_up(inc, d, 16);
+        if (r >= d) inc += v;
+    }
+    unsigned bt = 0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        unsigned long long ball = __ballot((mask >> m) & 1u);
+        unsigned mine = (unsigned)(ball >> (16 * grp)) & 0xFFFFu;
+        if (r == m) bt = mine;
+    }
+    if (live) {
+        masks[16 * t + r] = (uint16_t)mask;
+        rowptr[16 * t + r] = (uint8_t)(inc - cnt);
+        masks_t[16 * t + r] = (uint16_t)bt;
+    }
+}
+
+// a7 (spgemm.cu:986-1031): tile-level CSR from the sorted tile list -- boundary fill, no
+// reduce_by_key / scatter / scan needed.
+__global__ void conv_tile_csr_kernel(const long long *__restrict__ tile_keys, long long ntiles, int tile_rows,
+                                     int *__restrict__ tile_rowptr, int *__restrict__ tile_colidx)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    long long k = tile_keys[t];
+    int tr = (int)(k >> 32);
+    tile_colidx[t] = (int)(k & 0xFFFFFFFFll);
+    int prev = t > 0 ? (int)(tile_keys[t - 1] >> 32) : -1;
+    for (int row = prev + 1; row <= tr; ++row) tile_rowptr[row] = (int)t;
+    if (t == ntiles - 1)
+        for (int row = tr + 1; row <= tile_rows; ++row) tile_rowptr[row] = (int)ntiles;
+}
+
+// a7 (spgemm.cu:1033-1040): column-major re-sort keys, payload = CSR tile id
+__global__ void conv_csc_keys_kernel(const long long *__restrict__ tile_keys, long long ntiles, int bits_tr,
+                                     uint64_t *__restrict__ keys, uint32_t *__restrict__ perm)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    long long k = tile_keys[t];
+    keys[t] = ((uint64_t)(k & 0xFFFFFFFFll) << bits_tr) | (uint64_t)(k >> 32);
+    perm[t] = (uint32_t)t;
+}
+
+// a7 (spgemm.cu:1042-1061): tile-level CSC + _B_tileOffsets
+__global__ void conv_tile_csc_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm, long long ntiles,
+                                     int bits_tr, int tile_cols, int *__restrict__ tile_colptr, int *__restrict__ tile_rowidx,
+                                     int *__restrict__ tile_offsets)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    uint64_t k = keys[t];
+    int tc = (int)(k >> bits_tr);
+    tile_rowidx[t] = (int)(k & ((1ull << bits_tr) - 1ull));
+    tile_offsets[t] = (int)perm[t];
+    int prev = t > 0 ? (int)(keys[t - 1] >> bits_tr) : -1;
+    for (int col = prev + 1; col <= tc; ++col) tile_colptr[col] = (int)t;
+    if (t == ntiles - 1)
+        for (int col = tc + 1; col <= tile_cols; ++col) tile_colptr[col] = (int)ntiles;
+}
+
+// a8 flop count (spgemm.cu:1068-1079) without the host loop: flop = sum_k colnnz_A(k) * rownnz_B(k).
+// 16 lanes per tile row of B (lane = matrix row), resp. per tile column of A (lane = matrix column).
+__global__ void __launch_bounds__(256) flop_rownnz_kernel(const int *__restrict__ tile_rowptr, const uint16_t *__restrict__ masks,
+                                                          int tile_rows, int *__restrict__ rownnz)
+{
+    int tr = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    int r = threadIdx.x & 15;
+    if (tr >= tile_rows) return;
+    int cnt = 0;
+    for (int t = tile_rowptr[tr]; t < tile_rowptr[tr + 1]; ++t) cnt += __popc((unsigned)masks[16 * (size_t)t + r]);
+    rownnz[16 * (size_t)tr + r] = cnt;
+}
+
+__global__ void __launch_bounds__(256) flop_colnnz_kernel(const int *__restrict__ tile_colptr, const int *__restrict__ tile_offsets,
+                                                          const uint16_t *__restrict__ masks_t, int tile_cols, int *__restrict__ colnnz)
+{
+    int tc = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    int c = threadIdx.x & 15;
+    if (tc >= tile_cols) return;
+    int cnt = 0;
+    for (int p = tile_colptr[tc]; p < tile_colptr[tc + 1]; ++p)
+        cnt += __popc((unsigned)masks_t[16 * (size_t)tile_offsets[p] + c]);
+    colnnz[16 * (size_t)tc + c] = cnt;
+}
+
+__global__ void __launch_bounds__(256) flop_dot_kernel(const int *__restrict__ colnnz_a, const int *__restrict__ rownnz_b, size_t n,
+                                                       unsigned long long *__restrict__ out)
+{
+    __shared__ unsigned long long wsum[4];
+    unsigned long long s = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        s += (unsigned long long)colnnz_a[i] * (unsigned long long)rownnz_b[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, wsum[0] + wsum[1] + wsum[2] + wsum[3]);   // integer sum: order-independent
+}
+
+// ------------------------------------------------------------------------------------------
+// contexts
+// ------------------------------------------------------------------------------------------
+extern "C" pem_status pem_ctx_create_on_stream(int device, void *stream, pem_ctx **out)
+{
+    if (!out) return PEM_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available (%s); this library has no CPU fallback", e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return PEM_E_NODEVICE;
+    }
+    if (device < 0 || device >= ndev) {
+        set_error("device %d out of range (%d devices)", device, ndev);
+        return PEM_E_INVALID;
+    }
+    PEM_HIP(hipSetDevice(device));
+    pem_ctx *ctx = new pem_ctx();
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    } else {
+        PEM_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    PEM_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalars), sizeof(int64_t) * 64, hipHostMallocDefault));
+    PEM_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_scalars), sizeof(int64_t) * 64));
+    PEM_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_flags), sizeof(int) * NUM_FLAGS));
+    PEM_HIP(hipMemsetAsync(ctx->d_scalars, 0, sizeof(int64_t) * 64, ctx->stream));
+    PEM_HIP(hipMemsetAsync(ctx->d_flags, 0, sizeof(int) * NUM_FLAGS, ctx->stream));
+    for (auto &ev : ctx->ev) PEM_HIP(hipEventCreate(&ev));
+    PEM_HIP(hipStreamSynchronize(ctx->stream));
+    *out = ctx;
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_ctx_create(int device, pem_ctx **out) { return pem_ctx_create_on_stream(device, nullptr, out); }
+
+extern "C" pem_status pem_ctx_destroy(pem_ctx *ctx)
+{
+    if (!ctx) return PEM_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &s : ctx->pending) {
+        (void)hipEventDestroy(s.e0);
+        (void)hipEventDestroy(s.e1);
+    }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (auto e : ctx->ev) (void)hipEventDestroy(e);
+    (void)hipHostFree(ctx->h_scalars);
+    (void)hipFree(ctx->d_scalars);
+    (void)hipFree(ctx->d_flags);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_ctx_synchronize(pem_ctx *ctx)
+{
+    if (!ctx) return PEM_E_INVALID;
+    PEM_HIP(hipStreamSynchronize(ctx->stream));
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_get_timings(pem_ctx *ctx, pem_timings *t)
+{
+    if (!ctx || !t) return PEM_E_INVALID;
+    *t = ctx->timings;
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_set_kernel_profiling(pem_ctx *ctx, int enabled)
+{
+    if (!ctx) return PEM_E_INVALID;
+    PEM_TRY(resolve_kernel_spans(ctx));
+    ctx->profiling = enabled != 0;
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_reset_kernel_stats(pem_ctx *ctx)
+{
+    if (!ctx) return PEM_E_INVALID;
+    PEM_TRY(resolve_kernel_spans(ctx));
+    ctx->stats.clear();
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_kernel_stats_count(pem_ctx *ctx, int *n)
+{
+    if (!ctx || !n) return PEM_E_INVALID;
+    PEM_TRY(resolve_kernel_spans(ctx));
+    *n = (int)ctx->stats.size();
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_kernel_stats_get(pem_ctx *ctx, int idx, char *name, int name_cap, int64_t *calls, double *total_ms)
+{
+    if (!ctx || idx < 0 || idx >= (int)ctx->stats.size()) return PEM_E_INVALID;
+    const KernelStat &s = ctx->stats[idx];
+    if (name && name_cap > 0) {
+        strncpy(name, s.name.c_str(), (size_t)name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (calls) *calls = s.calls;
+    if (total_ms) *total_ms = s.total_ms;
+    return PEM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// conversion driver
+// ------------------------------------------------------------------------------------------
+// keys/perm already filled in k0/v0 (nnz entries); V = device values in input order.
+static pem_status build_tiled(pem_ctx *ctx, pem_tiled *T, DevBuf &k0, DevBuf &k1, DevBuf &v0, DevBuf &v1, const double *dV,
+                              int bits_tr, int bits_tc)
+{
+    const size_t nnz = (size_t)T->nnz;
+    hipStream_t st = ctx->stream;
+    uint64_t *keys = k0.as<uint64_t>();
+    uint32_t *perm = v0.as<uint32_t>();
+    PEM_TRY(radix_sort_u64_u32(ctx, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint32_t>(), v1.as<uint32_t>(), nnz,
+                               8 + bits_tc + bits_tr, &keys, &perm));
+    // tile heads -> exclusive scan -> T
+    DevBuf &head = ctx->tmp[0];
+    PEM_TRY(head.reserve(sizeof(int) * (nnz + 4)));
+    if (nnz) PEM_LAUNCH(ctx, conv_heads_kernel, grid_for(nnz, 256), 256, keys, nnz, head.as<int>(), ctx->d_flags);
+    PEM_TRY(exclusive_scan_i32(ctx, head.as<int>(), head.as<int>(), nnz, ctx->d_scalars));
+    int64_t ntiles = 0;
+    PEM_TRY(read_scalars(ctx, ctx->d_scalars, 1, &ntiles));
+    int hf[NUM_FLAGS];
+    PEM_TRY(read_flags(ctx, hf));
+    if (hf[FLAG_RANGE]) {
+        set_error("index out of range for a %d x %d matrix", T->rows, T->cols);
+        return PEM_E_INVALID;
+    }
+    if (hf[FLAG_DUP]) {
+        set_error("duplicate (row, col) entries in the input");
+        return PEM_E_DUPLICATE;
+    }
+    T->ntiles = ntiles;
+    const size_t nt = (size_t)ntiles;
+    PEM_TRY(T->tile_keys.reserve(sizeof(long long) * (nt + 1)));
+    PEM_TRY(T->tile_nnz_ptr.reserve(sizeof(int) * (nt + 4)));
+    PEM_TRY(T->vals.reserve(sizeof(double) * (nnz + 1)));
+    PEM_TRY(T->rowcolidx.reserve(nnz + 16));
+    PEM_TRY(T->masks.reserve(sizeof(uint16_t) * 16 * (nt + 1)));
+    PEM_TRY(T->masks_t.reserve(sizeof(uint16_t) * 16 * (nt + 1)));
+    PEM_TRY(T->rowptr.reserve(16 * (nt + 1)));
+    PEM_TRY(T->tile_rowptr.reserve(sizeof(int) * ((size_t)T->tile_rows + 4)));
+    PEM_TRY(T->tile_colidx.reserve(sizeof(int) * (nt + 4)));
+    PEM_TRY(T->tile_colptr.reserve(sizeof(int) * ((size_t)T->tile_cols + 4)));
+    PEM_TRY(T->tile_rowidx.reserve(sizeof(int) * (nt + 4)));
+    PEM_TRY(T->tile_offsets.reserve(sizeof(int) * (nt + 4)));
+    PEM_HIP(hipMemsetAsync(T->tile_nnz_ptr.p, 0, sizeof(int) * (nt + 1), st));
+    PEM_HIP(hipMemsetAsync(T->tile_rowptr.p, 0, sizeof(int) * ((size_t)T->tile_rows + 1), st));
+    PEM_HIP(hipMemsetAsync(T->tile_colptr.p, 0, sizeof(int) * ((size_t)T->tile_cols + 1), st));
+    PEM_HIP(hipEventRecord(ctx->ev[6], st));
+    if (nnz) {
+        PEM_LAUNCH(ctx, conv_fill_kernel, grid_for(nnz, 256), 256, keys, perm, head.as<int>(), nnz, dV, bits_tc, T->vals.as<double>(),
+                   T->rowcolidx.as<uint8_t>(), T->tile_keys.as<long long>(), T->tile_nnz_ptr.as<int>());
+        PEM_LAUNCH(ctx, conv_tile_meta_kernel, grid_for(nt * 16, 256), 256, T->rowcolidx.as<uint8_t>(), T->tile_nnz_ptr.as<int>(),
+                   (long long)ntiles, T->masks.as<uint16_t>(), T->rowptr.as<uint8_t>(), T->masks_t.as<uint16_t>());
+    }
+    PEM_HIP(hipEventRecord(ctx->ev[7], st));
+    if (nt) {
+        PEM_LAUNCH(ctx, conv_tile_csr_kernel, grid_for(nt, 256), 256, T->tile_keys.as<long long>(), (long long)ntiles, T->tile_rows,
+                   T->tile_rowptr.as<int>(), T->tile_colidx.as<int>());
+        // column-major order of the tiles: second (small) radix sort, payload = CSR tile id
+        PEM_TRY(k0.reserve(sizeof(uint64_t) * nt));
+        PEM_TRY(k1.reserve(sizeof(uint64_t) * nt));
+        PEM_TRY(v0.reserve(sizeof(uint32_t) * nt));
+        PEM_TRY(v1.reserve(sizeof(uint32_t) * nt));
+        PEM_LAUNCH(ctx, conv_csc_keys_kernel, grid_for(nt, 256), 256, T->tile_keys.as<long long>(), (long long)ntiles, bits_tr,
+                   k0.as<uint64_t>(), v0.as<uint32_t>());
+        uint64_t *ck = nullptr;
+        uint32_t *cp = nullptr;
+        PEM_TRY(radix_sort_u64_u32(ctx, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint32_t>(), v1.as<uint32_t>(), nt, bits_tr + bits_tc,
+                                   &ck, &cp));
+        PEM_LAUNCH(ctx, conv_tile_csc_kernel, grid_for(nt, 256), 256, ck, cp, (long long)ntiles, bits_tr, T->tile_cols,
+                   T->tile_colptr.as<int>(), T->tile_rowidx.as<int>(), T->tile_offsets.as<int>());
+    }
+    T->h_tile_rowptr.assign((size_t)T->tile_rows + 1, 0);
+    PEM_HIP(hipMemcpyAsync(T->h_tile_rowptr.data(), T->tile_rowptr.p, sizeof(int) * ((size_t)T->tile_rows + 1), hipMemcpyDeviceToHost, st));
+    PEM_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) T->conv_tile_kernel_ms = ms;
+    return PEM_OK;
+}
+
+static pem_status tiled_from_device(pem_ctx *ctx, int rows, int cols, int64_t nnz, const int *dI, const int *dJ, const int *d_rowptr,
+                                    const double *dV, int transpose, pem_tiled **out)
+{
+    if (!ctx || !out || rows <= 0 || cols <= 0 || nnz < 0) {
+        set_error("pem_tiled_from_*: bad arguments (rows=%d cols=%d nnz=%lld)", rows, cols, (long long)nnz);
+        return PEM_E_INVALID;
+    }
+    if (nnz > 0x7FFFFFFFll) {
+        set_error("nnz=%lld exceeds the reference's int32 index range", (long long)nnz);
+        return PEM_E_OVERFLOW;
+    }
+    *out = nullptr;
+    PEM_HIP(hipSetDevice(ctx->device));
+    auto t0 = std::chrono::high_resolution_clock::now();
+    pem_tiled *T = new pem_tiled();
+    T->rows = transpose ? cols : rows;
+    T->cols = transpose ? rows : cols;
+    T->nnz = nnz;
+    T->tile_rows = (T->rows + 15) / 16;
+    T->tile_cols = (T->cols + 15) / 16;
+    const int bits_tr = bits_for((uint64_t)T->tile_rows), bits_tc = bits_for((uint64_t)T->tile_cols);
+    pem_status s = PEM_OK;
+    {
+        DevBuf k0, k1, v0, v1;
+        const size_t n = (size_t)nnz;
+        s = zero_flags(ctx);
+        if (s == PEM_OK) s = k0.reserve(sizeof(uint64_t) * (n + 1));
+        if (s == PEM_OK) s = k1.reserve(sizeof(uint64_t) * (n + 1));
+        if (s == PEM_OK) s = v0.reserve(sizeof(uint32_t) * (n + 1));
+        if (s == PEM_OK) s = v1.reserve(sizeof(uint32_t) * (n + 1));
+        if (s == PEM_OK && n) {
+            if (d_rowptr)
+                PEM_LAUNCH(ctx, conv_csr_keys_kernel, grid_for((size_t)rows, 256), 256, d_rowptr, dJ, rows, cols, bits_tc, k0.as<uint64_t>(),
+                           v0.as<uint32_t>(), ctx->d_flags);
+            else
+                PEM_LAUNCH(ctx, conv_make_keys_kernel, grid_for(n, 256), 256, dI, dJ, n, T->rows, T->cols, transpose, bits_tc,
+                           k0.as<uint64_t>(), v0.as<uint32_t>(), ctx->d_flags);
+        }
+        if (s == PEM_OK) s = build_tiled(ctx, T, k0, k1, v0, v1, dV, bits_tr, bits_tc);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (s != PEM_OK) {
+        delete T;
+        return s;
+    }
+    T->conv_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    *out = T;
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_tiled_from_coo_device(pem_ctx *ctx, int rows, int cols, int64_t nnz, const int32_t *dI, const int32_t *dJ,
+                                                const double *dV, int transpose, pem_tiled **out)
+{
+    if (nnz > 0 && (!dI || !dJ || !dV)) return PEM_E_INVALID;
+    return tiled_from_device(ctx, rows, cols, nnz, dI, dJ, nullptr, dV, transpose, out);
+}
+
+extern "C" pem_status pem_tiled_from_coo(pem_ctx *ctx, int rows, int cols, int64_t nnz, const int32_t *I, const int32_t *J,
+                                         const double *V, int transpose, pem_tiled **out)
+{
+    if (!ctx || nnz < 0 || (nnz > 0 && (!I || !J || !V))) return PEM_E_INVALID;
+    PEM_HIP(hipSetDevice(ctx->device));
+    DevBuf dI, dJ, dV;
+    const size_t n = (size_t)nnz;
+    PEM_TRY(dI.reserve(sizeof(int) * (n + 1)));
+    PEM_TRY(dJ.reserve(sizeof(int) * (n + 1)));
+    PEM_TRY(dV.reserve(sizeof(double) * (n + 1)));
+    if (n) {   // H2D of the COO triplets (spgemm.cu:832-838)
+        PEM_HIP(hipMemcpyAsync(dI.p, I, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+        PEM_HIP(hipMemcpyAsync(dJ.p, J, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+        PEM_HIP(hipMemcpyAsync(dV.p, V, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    pem_status s = tiled_from_device(ctx, rows, cols, nnz, dI.as<int>(), dJ.as<int>(), nullptr, dV.as<double>(), transpose, out);
+    (void)hipStreamSynchronize(ctx->stream);
+    return s;
+}
+
+extern "C" pem_status pem_tiled_from_csr(pem_ctx *ctx, int rows, int cols, const int32_t *rowptr, const int32_t *colidx, const double *V,
+                                         pem_tiled **out)
+{
+    if (!ctx || !rowptr || rows <= 0) return PEM_E_INVALID;
+    for (int r = 0; r < rows; ++r)
+        if (rowptr[r + 1] < rowptr[r] || rowptr[0] != 0) {
+            set_error("pem_tiled_from_csr: rowptr is not a non-decreasing sequence starting at 0");
+            return PEM_E_INVALID;
+        }
+    const int64_t nnz = rowptr[rows];
+    if (nnz > 0 && (!colidx || !V)) return PEM_E_INVALID;
+    PEM_HIP(hipSetDevice(ctx->device));
+    DevBuf dR, dJ, dV;
+    const size_t n = (size_t)nnz;
+    PEM_TRY(dR.reserve(sizeof(int) * ((size_t)rows + 1)));
+    PEM_TRY(dJ.reserve(sizeof(int) * (n + 1)));
+    PEM_TRY(dV.reserve(sizeof(double) * (n + 1)));
+    PEM_HIP(hipMemcpyAsync(dR.p, rowptr, sizeof(int) * ((size_t)rows + 1), hipMemcpyHostToDevice, ctx->stream));
+    if (n) {
+        PEM_HIP(hipMemcpyAsync(dJ.p, colidx, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
+        PEM_HIP(hipMemcpyAsync(dV.p, V, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    pem_status s = tiled_from_device(ctx, rows, cols, nnz, nullptr, dJ.as<int>(), dR.as<int>(), dV.as<double>(), 0, out);
+    (void)hipStreamSynchronize(ctx->stream);
+    return s;
+}
+
+extern "C" pem_status pem_tiled_destroy(pem_ctx *ctx, pem_tiled *t)
+{
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    delete t;
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_tiled_get_info(const pem_tiled *t, pem_tiled_info *info)
+{
+    if (!t || !info) return PEM_E_INVALID;
+    info->rows = t->rows;
+    info->cols = t->cols;
+    info->nnz = t->nnz;
+    info->tile_rows = t->tile_rows;
+    info->tile_cols = t->tile_cols;
+    info->ntiles = t->ntiles;
+    info->conv_ms = t->conv_ms;
+    info->conv_tile_kernel_ms = t->conv_tile_kernel_ms;
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_tiled_get_array(pem_ctx *ctx, const pem_tiled *t, pem_tiled_array which, void *host_dst, int64_t bytes)
+{
+    if (!ctx || !t || (!host_dst && bytes > 0)) return PEM_E_INVALID;
+    const size_t T = (size_t)t->ntiles, nnz = (size_t)t->nnz;
+    const void *src = nullptr;
+    size_t want = 0;
+    switch (which) {
+    case PEM_T_TILE_KEYS: src = t->tile_keys.p; want = 8 * T; break;
+    case PEM_T_TILE_NNZ_PTR: src = t->tile_nnz_ptr.p; want = 4 * (T + 1); break;
+    case PEM_T_MASKS: src = t->masks.p; want = 32 * T; break;
+    case PEM_T_ROWPTR: src = t->rowptr.p; want = 16 * T; break;
+    case PEM_T_ROWCOLIDX: src = t->rowcolidx.p; want = nnz; break;
+    case PEM_T_VALS: src = t->vals.p; want = 8 * nnz; break;
+    case PEM_T_MASKS_T: src = t->masks_t.p; want = 32 * T; break;
+    case PEM_T_TILE_ROWPTR: src = t->tile_rowptr.p; want = 4 * ((size_t)t->tile_rows + 1); break;
+    case PEM_T_TILE_COLIDX: src = t->tile_colidx.p; want = 4 * T; break;
+    case PEM_T_TILE_COLPTR: src = t->tile_colptr.p; want = 4 * ((size_t)t->tile_cols + 1); break;
+    case PEM_T_TILE_ROWIDX: src = t->tile_rowidx.p; want = 4 * T; break;
+    case PEM_T_TILE_OFFSETS: src = t->tile_offsets.p; want = 4 * T; break;
+    default: set_error("unknown pem_tiled_array %d", (int)which); return PEM_E_INVALID;
+    }
+    if ((size_t)bytes != want) {
+        set_error("pem_tiled_get_array(%d): caller passed %lld bytes, array has %zu", (int)which, (long long)bytes, want);
+        return PEM_E_INVALID;
+    }
+    if (want == 0) return PEM_OK;
+    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_HIP(hipMemcpyAsync(host_dst, src, want, hipMemcpyDeviceToHost, ctx->stream));
+    PEM_HIP(hipStreamSynchronize(ctx->stream));
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_flop_count(pem_ctx *ctx, const pem_tiled *A, const pem_tiled *B, uint64_t *flop)
+{
+    if (!ctx || !A || !B || !flop) return PEM_E_INVALID;
+    if (A->cols != B->rows) {
+        set_error("pem_flop_count: A is %d x %d, B is %d x %d", A->rows, A->cols, B->rows, B->cols);
+        return PEM_E_INVALID;
+    }
+    PEM_HIP(hipSetDevice(ctx->device));
+    const size_t n = 16 * (size_t)A->tile_cols;   // == 16 * B->tile_rows
+    DevBuf &ca = ctx->tmp[0], &rb = ctx->tmp[1];
+    PEM_TRY(ca.reserve(sizeof(int) * n + 16));
+    PEM_TRY(rb.reserve(sizeof(int) * n + 16));
+    PEM_HIP(hipMemsetAsync(ctx->d_scalars, 0, sizeof(int64_t), ctx->stream));
+    PEM_LAUNCH(ctx, flop_colnnz_kernel, grid_for(n, 256), 256, A->tile_colptr.as<int>(), A->tile_offsets.as<int>(), A->masks_t.as<uint16_t>(),
+               A->tile_cols, ca.as<int>());
+    PEM_LAUNCH(ctx, flop_rownnz_kernel, grid_for(n, 256), 256, B->tile_rowptr.as<int>(), B->masks.as<uint16_t>(), B->tile_rows, rb.as<int>());
+    PEM_LAUNCH(ctx, flop_dot_kernel, 256, 256, ca.as<int>(), rb.as<int>(), n, reinterpret_cast<unsigned long long *>(ctx->d_scalars));
+    int64_t v = 0;
+    PEM_TRY(read_scalars(ctx, ctx->d_scalars, 1, &v));
+    *flop = (uint64_t)v;
+    return PEM_OK;
+}

@@ -1,0 +1,182 @@
+// pem_internal.h -- shared host-side plumbing of libpemspgemm_hip.so (gfx950 only).
+// Replaces the reference's rmm pools / thrust allocators / 19 cudaEvents / 5 streams
+// (spgemm.cu:697-758, 808-817) with: one HIP stream per context, grow-only device buffers
+// owned by the handles, one pinned scalar page for size read-backs, and an event pool for
+// per-kernel timing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/pem_spgemm.h"
+
+namespace pem {
+
+void set_error(const char *fmt, ...);
+
+#define PEM_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            pem::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return PEM_E_HIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+#define PEM_TRY(expr)                     \
+    do {                                  \
+        pem_status _s = (expr);           \
+        if (_s != PEM_OK) return _s;      \
+    } while (0)
+
+// Grow-only device buffer.  Contents are NOT preserved across a growth.
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    pem_status reserve(size_t bytes)
+    {
+        if (bytes <= cap) return PEM_OK;
+        release();
+        size_t want = (bytes + 255) & ~size_t(255);
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+            return PEM_E_NOMEM;
+        }
+        cap = want;
+        return PEM_OK;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct KernelStat {
+    std::string name;
+    int64_t calls = 0;
+    double total_ms = 0.0;
+};
+
+struct PendingSpan {
+    int stat;
+    hipEvent_t e0, e1;
+};
+
+// device-side status words, zeroed at the start of every ABI call that launches kernels
+enum DevFlag { FLAG_RANGE = 0, FLAG_DUP = 1, FLAG_OVERFLOW = 2, FLAG_CAPACITY = 3, NUM_FLAGS = 8 };
+
+}  // namespace pem
+
+struct pem_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // pinned host page for scalar read-backs (replaces the reference's racy pageable
+    // cudaMemcpyAsync of _C_nnz / d_pairs_count / C_nnz)
+    int64_t *h_scalars = nullptr;      // 64 slots
+    int64_t *d_scalars = nullptr;      // 64 slots on the device
+    int *d_flags = nullptr;            // NUM_FLAGS ints
+    // shared temporaries (grow-only, reused by every call on this context)
+    pem::DevBuf scan_bsum;             // block sums of the device scan
+    pem::DevBuf sort_hist;             // radix-sort histograms
+    pem::DevBuf tmp[12];               // step/convert temporaries, see call sites
+    // timing
+    hipEvent_t ev[8] = {};             // step spans
+    pem_timings timings = {};
+    bool profiling = false;
+    std::vector<pem::KernelStat> stats;
+    std::vector<pem::PendingSpan> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace pem {
+
+// RAII kernel span: records two events around a launch when profiling is on.
+struct KernelSpan {
+    pem_ctx *ctx;
+    int stat = -1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    KernelSpan(pem_ctx *c, const char *name);
+    ~KernelSpan();
+};
+pem_status resolve_kernel_spans(pem_ctx *ctx);
+
+#define PEM_LAUNCH(ctx, kernel, grid, block, ...)                                              \
+    do {                                                                                       \
+        pem::KernelSpan _span((ctx), #kernel);                                                 \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__);    \
+    } while (0)
+
+#define PEM_LAUNCH_NAMED(ctx, name, kernel, grid, block, ...)                                  \
+    do {                                                                                       \
+        pem::KernelSpan _span((ctx), name);                                                    \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__);    \
+    } while (0)
+
+inline unsigned grid_for(size_t n, unsigned per_block)
+{
+    size_t g = (n + per_block - 1) / per_block;
+    return g == 0 ? 1u : (unsigned)g;
+}
+
+inline int bits_for(uint64_t count)   // bits needed to represent values in [0, count)
+{
+    int b = 0;
+    while (b < 63 && (uint64_t(1) << b) < count) ++b;
+    return b < 1 ? 1 : b;
+}
+
+// ---- device primitives (primitives.hip) -------------------------------------------------
+// out[0..n) = exclusive prefix sums of in[0..n), out[n] = total.  in == out allowed.
+// Both pointers 16-byte aligned.  Sets FLAG_OVERFLOW when the total exceeds INT32_MAX.
+// If d_total64 != nullptr the 64-bit total is also stored there.
+pem_status exclusive_scan_i32(pem_ctx *ctx, const int *in, int *out, size_t n, int64_t *d_total64);
+
+// Stable LSD radix sort of (key, payload) on key bits [0, nbits).  Buffers ping-pong; on
+// return *keys_out / *vals_out point at the buffers holding the sorted data.
+pem_status radix_sort_u64_u32(pem_ctx *ctx, uint64_t *k0, uint64_t *k1, uint32_t *v0, uint32_t *v1,
+                              size_t n, int nbits, uint64_t **keys_out, uint32_t **vals_out);
+
+pem_status zero_flags(pem_ctx *ctx);
+pem_status read_flags(pem_ctx *ctx, int *host_flags /*NUM_FLAGS*/);   // synchronises the stream
+// copy `count` int64 scalars from device to the pinned page and synchronise
+pem_status read_scalars(pem_ctx *ctx, const int64_t *d_src, int count, int64_t *host_dst);
+
+}  // namespace pem
+
+struct pem_tiled {
+    int rows = 0, cols = 0;
+    int64_t nnz = 0;
+    int tile_rows = 0, tile_cols = 0;
+    int64_t ntiles = 0;
+    double conv_ms = 0.0, conv_tile_kernel_ms = 0.0;
+    pem::DevBuf tile_keys, tile_nnz_ptr, masks, rowptr, rowcolidx, vals, masks_t;
+    pem::DevBuf tile_rowptr, tile_colidx, tile_colptr, tile_rowidx, tile_offsets;
+    std::vector<int> h_tile_rowptr;   // host copy (tile_rows+1 ints) for plan creation / splits
+};
+
+struct pem_cplan {
+    const pem_tiled *A = nullptr, *B = nullptr;
+    int tr_lo = 0, tr_hi = 0;
+    int a_lo = 0, a_hi = 0;            // A tile id range of the slice
+    int state = 0;                     // 0 created, 1 step1 done, 2 step2 done, 3 step3 done
+    int64_t ntiles_c = 0, npairs = 0, nnz_c = 0;
+    pem::DevBuf c_tile_rowptr, c_tile_rowidx, c_tile_colidx;
+    pem::DevBuf pairs_offset, pairs_a, pairs_b;
+    pem::DevBuf c_mask, c_tile_nnz_ptr, c_rowptr, c_rowcolidx, c_vals;
+    // step-1 products kept for step 2 (expanded pair ids + the sorted permutation)
+    pem::DevBuf prod_a, prod_b, aprod_off;
+    pem::DevBuf sk0, sk1, sv0, sv1;    // sort buffers
+    uint32_t *sorted_perm = nullptr;   // points into sv0/sv1
+};

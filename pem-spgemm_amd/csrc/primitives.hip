@@ -1,0 +1,357 @@
+// primitives.hip -- device-wide primitives for gfx950 (wave64), written once for the path.
+// Replaces thrust::exclusive_scan / thrust::sort / thrust::stable_sort / unique /
+// reduce_by_key call sites (spgemm.cu:869-927, 990-1061, 1168, 1242, 1288) and the warp
+// scan of NSPARSE/utils_cuda_scan.h:19-35.  No thrust, no rocPRIM: plain HIP.
+#include "pem_internal.h"
+#include <cstdarg>
+
+namespace pem {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+const char *last_error() { return g_err; }
+
+// ------------------------------------------------------------------------------------------
+// kernel spans
+// ------------------------------------------------------------------------------------------
+static hipEvent_t take_event(pem_ctx *ctx)
+{
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+KernelSpan::KernelSpan(pem_ctx *c, const char *name) : ctx(c)
+{
+    if (!ctx->profiling) return;
+    for (size_t i = 0; i < ctx->stats.size(); ++i)
+        if (ctx->stats[i].name == name) { stat = (int)i; break; }
+    if (stat < 0) {
+        ctx->stats.push_back(KernelStat{name, 0, 0.0});
+        stat = (int)ctx->stats.size() - 1;
+    }
+    e0 = take_event(ctx);
+    e1 = take_event(ctx);
+    (void)hipEventRecord(e0, ctx->stream);
+}
+KernelSpan::~KernelSpan()
+{
+    if (stat < 0) return;
+    (void)hipEventRecord(e1, ctx->stream);
+    ctx->pending.push_back(PendingSpan{stat, e0, e1});
+}
+
+pem_status resolve_kernel_spans(pem_ctx *ctx)
+{
+    if (ctx->pending.empty()) return PEM_OK;
+    PEM_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto &s : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.e0, s.e1) == hipSuccess) {
+            ctx->stats[s.stat].calls += 1;
+            ctx->stats[s.stat].total_ms += ms;
+        }
+        ctx->event_pool.push_back(s.e0);
+        ctx->event_pool.push_back(s.e1);
+    }
+    ctx->pending.clear();
+    return PEM_OK;
+}
+
+pem_status zero_flags(pem_ctx *ctx)
+{
+    PEM_HIP(hipMemsetAsync(ctx->d_flags, 0, sizeof(int) * NUM_FLAGS, ctx->stream));
+    return PEM_OK;
+}
+
+pem_status read_flags(pem_ctx *ctx, int *host_flags)
+{
+    int *h = reinterpret_cast<int *>(ctx->h_scalars + 48);
+    PEM_HIP(hipMemcpyAsync(h, ctx->d_flags, sizeof(int) * NUM_FLAGS, hipMemcpyDeviceToHost, ctx->stream));
+    PEM_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < NUM_FLAGS; ++i) host_flags[i] = h[i];
+    return PEM_OK;
+}
+
+pem_status read_scalars(pem_ctx *ctx, const int64_t *d_src, int count, int64_t *host_dst)
+{
+    PEM_HIP(hipMemcpyAsync(ctx->h_scalars, d_src, sizeof(int64_t) * count, hipMemcpyDeviceToHost, ctx->stream));
+    PEM_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < count; ++i) host_dst[i] = ctx->h_scalars[i];
+    return PEM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan: reduce-then-scan, 3 launches, 2 reads + 1 write of the data
+// ------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_TILE = SCAN_THREADS * 4;      // int4 per thread
+constexpr int SCAN_TILES_PER_BLOCK = 8;
+constexpr int SCAN_BLOCK_ITEMS = SCAN_TILE * SCAN_TILES_PER_BLOCK;
+
+template <typename T> __device__ __forceinline__ T wave_inclusive_scan(T v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ T wave_reduce_sum(T v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const int *__restrict__ in, size_t n,
+                                                                   long long *__restrict__ bsum)
+{
+    __shared__ long long wsum[SCAN_THREADS / 64];
+    size_t base = (size_t)blockIdx.x * SCAN_BLOCK_ITEMS;
+    size_t end = base + SCAN_BLOCK_ITEMS < n ? base + SCAN_BLOCK_ITEMS : n;
+    long long s = 0;
+    for (size_t i = base + threadIdx.x; i < end; i += SCAN_THREADS) s += in[i];
+    s = wave_reduce_sum(s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) t += wsum[w];
+        bsum[blockIdx.x] = t;
+    }
+}
+
+// single block: in-place exclusive scan of the block sums; total -> bsum[nblk], *total64, overflow flag
+__global__ void __launch_bounds__(1024) scan_bsums_kernel(long long *__restrict__ bsum, int nblk,
+                                                          long long *__restrict__ total64, int *__restrict__ flags)
+{
+    __shared__ long long wsum[16];
+    __shared__ long long carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        int i = base + threadIdx.x;
+        long long v = i < nblk ? bsum[i] : 0;
+        long long inc = wave_inclusive_scan(v);
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        long long woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+        long long carry = carry_s;
+        if (i < nblk) bsum[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        long long t = carry_s;
+        bsum[nblk] = t;
+        if (total64) *total64 = t;
+        if (t > 0x7FFFFFFFLL) flags[FLAG_OVERFLOW] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const int *in, int *out, size_t n,
+                                                                  const long long *__restrict__ bsum, int nblk)
+{
+    __shared__ int wsum[SCAN_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long carry = bsum[blockIdx.x];
+    size_t base = (size_t)blockIdx.x * SCAN_BLOCK_ITEMS;
+    for (int tile = 0; tile < SCAN_TILES_PER_BLOCK; ++tile, base += SCAN_TILE) {
+        if (base >= n) break;
+        size_t i0 = base + (size_t)threadIdx.x * 4;
+        int v[4];
+        if (i0 + 4 <= n) {
+            int4 q = *reinterpret_cast<const int4 *>(in + i0);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? in[i0 + k] : 0;
+        }
+        int tsum = v[0] + v[1] + v[2] + v[3];
+        int inc = wave_inclusive_scan(tsum);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int woff = 0, btotal = 0;
+#pragma unroll
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+            int s = wsum[w];
+            if (w < wave) woff += s;
+            btotal += s;
+        }
+        int ex = (int)carry + woff + inc - tsum;
+        int o0 = ex, o1 = o0 + v[0], o2 = o1 + v[1], o3 = o2 + v[2];
+        if (i0 + 4 <= n) {
+            *reinterpret_cast<int4 *>(out + i0) = make_int4(o0, o1, o2, o3);
+        } else {
+            if (i0 < n) out[i0] = o0;
+            if (i0 + 1 < n) out[i0 + 1] = o1;
+            if (i0 + 2 < n) out[i0 + 2] = o2;
+        }
+        carry += btotal;
+        __syncthreads();
+    }
+    if (blockIdx.x == nblk - 1 && threadIdx.x == 0) out[n] = (int)bsum[nblk];
+}
+
+__global__ void scan_empty_kernel(int *out, long long *total64)
+{
+    out[0] = 0;
+    if (total64) *total64 = 0;
+}
+
+pem_status exclusive_scan_i32(pem_ctx *ctx, const int *in, int *out, size_t n, int64_t *d_total64)
+{
+    if (n == 0) {
+        PEM_LAUNCH(ctx, scan_empty_kernel, 1, 1, out, reinterpret_cast<long long *>(d_total64));
+        return PEM_OK;
+    }
+    if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) {
+        set_error("exclusive_scan_i32: unaligned pointer");
+        return PEM_E_INVALID;
+    }
+    int nblk = (int)((n + SCAN_BLOCK_ITEMS - 1) / SCAN_BLOCK_ITEMS);
+    PEM_TRY(ctx->scan_bsum.reserve(sizeof(long long) * ((size_t)nblk + 1)));
+    long long *bsum = ctx->scan_bsum.as<long long>();
+    PEM_LAUNCH(ctx, scan_reduce_kernel, nblk, SCAN_THREADS, in, n, bsum);
+    PEM_LAUNCH(ctx, scan_bsums_kernel, 1, 1024, bsum, nblk, reinterpret_cast<long long *>(d_total64), ctx->d_flags);
+    PEM_LAUNCH(ctx, scan_apply_kernel, nblk, SCAN_THREADS, in, out, n, bsum, nblk);
+    return PEM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// LSD radix sort, 8 bits per pass, stable.  Per pass: block histograms -> device scan ->
+// scatter.  A block = 4 waves x 16 rounds x 64 keys; ranks come from wave64 ballots
+// (match-any on the digit), so there are no atomics in the scatter.
+// ------------------------------------------------------------------------------------------
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_ROUNDS = 16;
+constexpr int RS_WAVE_ITEMS = RS_ROUNDS * 64;
+constexpr int RS_BLOCK_ITEMS = RS_WAVE_ITEMS * RS_WAVES;
+
+__global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint64_t *__restrict__ keys, size_t n, int shift,
+                                                             int *__restrict__ hist, int nblk)
+{
+    __shared__ int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    size_t base = (size_t)blockIdx.x * RS_BLOCK_ITEMS;
+    size_t end = base + RS_BLOCK_ITEMS < n ? base + RS_BLOCK_ITEMS : n;
+    for (size_t i = base + threadIdx.x; i < end; i += RS_THREADS) atomicAdd(&h[(keys[i] >> shift) & 255], 1);
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+// lanes holding the same digit as this lane (restricted to `valid` lanes)
+__device__ __forceinline__ unsigned long long match_digit(unsigned d, unsigned long long valid)
+{
+    unsigned long long peers = valid;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        unsigned long long m = __ballot((d >> b) & 1);
+        peers &= ((d >> b) & 1) ? m : ~m;
+    }
+    return peers;
+}
+
+__global__ void __launch_bounds__(RS_THREADS) rs_scatter_kernel(const uint64_t *__restrict__ kin, uint64_t *__restrict__ kout,
+                                                                const uint32_t *__restrict__ vin, uint32_t *__restrict__ vout,
+                                                                size_t n, int shift, const int *__restrict__ goff, int nblk)
+{
+    __shared__ int wcnt[RS_WAVES][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int w = 0; w < RS_WAVES; ++w) wcnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const size_t wbase = (size_t)blockIdx.x * RS_BLOCK_ITEMS + (size_t)wave * RS_WAVE_ITEMS;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint64_t k[RS_ROUNDS];
+    // phase 1: per-wave digit counts
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        size_t idx = wbase + (size_t)r * 64 + lane;
+        bool valid = idx < n;
+        k[r] = valid ? kin[idx] : ~0ull;
+        unsigned d = (unsigned)(k[r] >> shift) & 255u;
+        unsigned long long vm = __ballot(valid);
+        unsigned long long peers = match_digit(d, vm);
+        if (valid && (peers & lt) == 0) wcnt[wave][d] += __popcll(peers);   // lowest lane of each digit group
+    }
+    __syncthreads();
+    // phase 2: thread d turns the 4 wave counts of digit d into running global positions
+    {
+        int run = goff[(size_t)threadIdx.x * nblk + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) {
+            int c = wcnt[w][threadIdx.x];
+            wcnt[w][threadIdx.x] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    // phase 3: rank inside the round by ballot, scatter
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        size_t idx = wbase + (size_t)r * 64 + lane;
+        bool valid = idx < n;
+        unsigned d = (unsigned)(k[r] >> shift) & 255u;
+        unsigned long long vm = __ballot(valid);
+        unsigned long long peers = match_digit(d, vm);
+        int start = valid ? wcnt[wave][d] : 0;
+        int pos = start + __popcll(peers & lt);
+        if (valid && (peers & lt) == 0) wcnt[wave][d] = start + __popcll(peers);
+        if (valid) {
+            kout[pos] = k[r];
+            vout[pos] = vin[idx];
+        }
+    }
+}
+
+pem_status radix_sort_u64_u32(pem_ctx *ctx, uint64_t *k0, uint64_t *k1, uint32_t *v0, uint32_t *v1, size_t n, int nbits,
+                              uint64_t **keys_out, uint32_t **vals_out)
+{
+    *keys_out = k0;
+    *vals_out = v0;
+    if (n <= 1 || nbits <= 0) return PEM_OK;
+    if (n > 0x7FFFFFFFull) {
+        set_error("radix_sort: %zu items exceed int32 positions", n);
+        return PEM_E_OVERFLOW;
+    }
+    int nblk = (int)((n + RS_BLOCK_ITEMS - 1) / RS_BLOCK_ITEMS);
+    size_t hcount = (size_t)256 * nblk;
+    PEM_TRY(ctx->sort_hist.reserve(sizeof(int) * (hcount + 4)));
+    int *hist = ctx->sort_hist.as<int>();
+    uint64_t *kin = k0, *kout = k1;
+    uint32_t *vin = v0, *vout = v1;
+    for (int shift = 0; shift < nbits; shift += 8) {
+        PEM_LAUNCH(ctx, rs_hist_kernel, nblk, RS_THREADS, kin, n, shift, hist, nblk);
+        PEM_TRY(exclusive_scan_i32(ctx, hist, hist, hcount, nullptr));
+        PEM_LAUNCH(ctx, rs_scatter_kernel, nblk, RS_THREADS, kin, kout, vin, vout, n, shift, hist, nblk);
+        uint64_t *tk = kin; kin = kout; kout = tk;
+        uint32_t *tv = vin; vin = vout; vout = tv;
+    }
+    *keys_out = kin;
+    *vals_out = vin;
+    return PEM_OK;
+}
+
+}  // namespace pem
+
+extern "C" const char *pem_last_error(void) { return pem::last_error(); }
+extern "C" const char *pem_version(void) { return "pem-spgemm_amd 0.1 (gfx950)"; }

@@ -1,0 +1,635 @@
+// spgemm.hip -- rows a9-a14: the three-step tiled SpGEMM hot path and the C export.
+//
+// Reference: step 1 = SPA bitmask kernels run twice (count + emit) or the NSPARSE binned
+// hash path (spgemm.cu:1141-1218); step 2a/2b = warp-per-C-tile list intersection by binary
+// search, again run twice (spgemm.cu:387-497); step 2c/2d masks + intra-tile CSR
+// (spgemm.cu:499-591); step 3 numeric with a global read-modify-write per product
+// (spgemm.cu:593-661).
+//
+// Here (v0 of the MI355X design): the tile-level product is expanded once -- every
+// (A tile, B tile) pair with matching k is a product with key (C tile row, C tile col) --
+// and ONE stable radix sort groups the products by C tile in ascending k.  The C tile list
+// (step 1) and the pair lists (step 2a/2b) are two views of that sorted stream: no SPA, no
+// hash tables, no binary searches, nothing computed twice.  Step 2c uses the boolean row
+// product (C row r = OR of B rows kk over kk in A row r) on 16-lane groups; step 3 keeps one
+// C entry per lane in a register and stores it once.  All outputs keep the reference layouts.
+#include "pem_internal.h"
+#include <chrono>
+
+using namespace pem;
+
+// ------------------------------------------------------------------------------------------
+// step 1
+// ------------------------------------------------------------------------------------------
+// per A tile (i,k): number of tiles in B's tile row k (= tile-level intermediate products;
+// the quantity of spgemm_nsparse_kernel.h:135-151 per A tile instead of per row)
+__global__ void s1_aprod_kernel(const int *__restrict__ a_tile_colidx, int a_lo, int nA, const int *__restrict__ b_tile_rowptr,
+                                int *__restrict__ aprod)
+{
+    int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nA) return;
+    int k = a_tile_colidx[a_lo + a];
+    aprod[a] = b_tile_rowptr[k + 1] - b_tile_rowptr[k];
+}
+
+// expand: 16 lanes per A tile walk B's tile row k; product p gets key (i - tr_lo, j)
+__global__ void __launch_bounds__(256) s1_expand_kernel(const long long *__restrict__ a_tile_keys, int a_lo, int nA,
+                                                        const int *__restrict__ aprod_off, const int *__restrict__ b_tile_rowptr,
+                                                        const int *__restrict__ b_tile_colidx, int tr_lo, int bits_tc,
+                                                        uint64_t *__restrict__ keys, uint32_t *__restrict__ perm,
+                                                        int *__restrict__ prod_a, int *__restrict__ prod_b)
+{
+    int arel = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    int l = threadIdx.x & 15;
+    if (arel >= nA) return;
+    int a = a_lo + arel;
+    long long ak = a_tile_keys[a];
+    int i = (int)(ak >> 32), k = (int)(ak & 0xFFFFFFFFll);
+    int b0 = b_tile_rowptr[k], len = b_tile_rowptr[k + 1] - b0;
+    int p0 = aprod_off[arel];
+    uint64_t hi = (uint64_t)(unsigned)(i - tr_lo) << bits_tc;
+    for (int q = l; q < len; q += 16) {
+        int p = p0 + q;
+        keys[p] = hi | (uint64_t)(unsigned)b_tile_colidx[b0 + q];
+        perm[p] = (uint32_t)p;
+        prod_a[p] = a;
+        prod_b[p] = b0 + q;
+    }
+}
+
+__global__ void s1_heads_kernel(const uint64_t *__restrict__ keys, size_t n, int *__restrict__ head)
+{
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    head[p] = (p == 0) || (keys[p] != keys[p - 1]);
+}
+
+// C tile list (spgemm.cu:374-381 output contract: ascending tile column inside a tile row)
+// + pair offsets (spgemm.cu:483-484 + :1242): both read off the sorted product stream.
+__global__ void s1_emit_ctiles_kernel(const uint64_t *__restrict__ keys, const int *__restrict__ headx, size_t n, int tr_lo, int bits_tc,
+                                      int *__restrict__ c_rowidx, int *__restrict__ c_colidx, int *__restrict__ pairs_offset)
+{
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int t = headx[p];
+    if (headx[p + 1] != t) {
+        uint64_t k = keys[p];
+        c_rowidx[t] = (int)(k >> bits_tc) + tr_lo;
+        c_colidx[t] = (int)(k & ((1ull << bits_tc) - 1ull));
+        pairs_offset[t] = (int)p;
+    }
+    if (p == n - 1) pairs_offset[headx[n]] = (int)n;
+}
+
+// _C_rowPtr (spgemm.cu:1166-1168) by boundary fill over the sorted C tile rows
+__global__ void s1_c_rowptr_kernel(const int *__restrict__ c_rowidx, long long ntc, int tr_lo, int mt, int *__restrict__ c_rowptr)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntc) return;
+    int tr = c_rowidx[t] - tr_lo;
+    int prev = t > 0 ? c_rowidx[t - 1] - tr_lo : -1;
+    for (int row = prev + 1; row <= tr; ++row) c_rowptr[row] = (int)t;
+    if (t == ntc - 1)
+        for (int row = tr + 1; row <= mt; ++row) c_rowptr[row] = (int)ntc;
+}
+
+// ------------------------------------------------------------------------------------------
+// step 2
+// ------------------------------------------------------------------------------------------
+// a10 pairs_a / pairs_b (spgemm.cu:423-432): gather the expanded ids through the sort permutation
+__global__ void s2_pairs_kernel(const uint32_t *__restrict__ perm, const int *__restrict__ prod_a, const int *__restrict__ prod_b, size_t n,
+                                int *__restrict__ pairs_a, int *__restrict__ pairs_b)
+{
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint32_t q = perm[p];
+    pairs_a[p] = prod_a[q];
+    pairs_b[p] = prod_b[q];
+}
+
+// a11 (spgemm.cu:499-550).  16 lanes per C tile, lane = tile row r.  For every pair the C row
+// is OR_{kk in Amask[r]} Bmask[kk] -- work proportional to the A tile's nnz, not 16x16 ANDs.
+// Stored in the reference's packing: uint32 word q = (row 2q)<<16 | row 2q+1, i.e. the
+// uint16 at index r^1.
+__global__ void __launch_bounds__(256) s2_cmask_kernel(const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a,
+                                                       const int *__restrict__ pairs_b, long long ntc,
+                                                       const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks,
+                                                       uint16_t *__restrict__ c_mask16, int *__restrict__ c_tile_nnz)
+{
+    long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int r = threadIdx.x & 15;
+    const bool live = t < ntc;
+    unsigned cm = 0;
+    if (live) {
+        int p0 = pairs_offset[t], p1 = pairs_offset[t + 1];
+        for (int p = p0; p < p1; ++p) {
+            int a = pairs_a[p], b = pairs_b[p];
+            unsigned am = a_masks[16 * (size_t)a + r];
+            const uint16_t *bm = b_masks + 16 * (size_t)b;
+            while (am) {
+                int kk = __builtin_ctz(am);
+                am &= am - 1;
+                cm |= bm[kk];
+            }
+        }
+    }
+    int cnt = __popc(cm);
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 16);
+    if (live) {
+        c_mask16[16 * t + (r ^ 1)] = (uint16_t)cm;
+        if (r == 0) c_tile_nnz[t] = cnt;
+    }
+}
+
+// a12 (spgemm.cu:552-591): intra-tile row pointers + packed (r<<4|c) bytes
+__global__ void __launch_bounds__(256) s2_crowcol_kernel(const uint16_t *__restrict__ c_mask16, const int *__restrict__ c_tile_nnz_ptr,
+                                                         long long ntc, uint8_t *__restrict__ c_rowptr, uint8_t *__restrict__ c_rowcolidx)
+{
+    long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int r = threadIdx.x & 15;
+    const bool live = t < ntc;
+    unsigned cm = live ? c_mask16[16 * t + (r ^ 1)] : 0u;
+    int cnt = __popc(cm), inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        int v = __shfl_up(inc, d, 16);
+        if (r >= d) inc += v;
+    }
+    if (!live) return;
+    int off = inc - cnt;
+    c_rowptr[16 * t + r] = (uint8_t)off;
+    uint8_t *dst = c_rowcolidx + c_tile_nnz_ptr[t] + off;
+    while (cm) {
+        int c = __builtin_ctz(cm);
+        cm &= cm - 1;
+        *dst++ = (uint8_t)((r << 4) | c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// step 3 (spgemm.cu:593-661).  16 lanes per C tile, one C entry per lane (strided by 16);
+// pairs ascending in k-tile, bits of Amask[r] & BT[c] ascending, one fma per product, the
+// accumulator lives in a register and is stored once (no global RMW, no dependence on
+// zero-filled memory -- SURVEY 2.3 #1).
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) s3_accumulate_kernel(
+    const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b, long long ntc,
+    const int *__restrict__ c_tile_nnz_ptr, const uint8_t *__restrict__ c_rowcolidx, double *__restrict__ c_vals,
+    const int *__restrict__ a_nnz_ptr, const double *__restrict__ a_vals, const uint16_t *__restrict__ a_masks,
+    const uint8_t *__restrict__ a_rowptr, const int *__restrict__ b_nnz_ptr, const double *__restrict__ b_vals,
+    const uint16_t *__restrict__ b_masks, const uint8_t *__restrict__ b_rowptr, const uint16_t *__restrict__ b_masks_t)
+{
+    long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    if (t >= ntc) return;
+    const int off = c_tile_nnz_ptr[t], nnz_t = c_tile_nnz_ptr[t + 1] - off;
+    const int p0 = pairs_offset[t], p1 = pairs_offset[t + 1];
+    for (int n = l; n < nnz_t; n += 16) {
+        const unsigned rc = c_rowcolidx[off + n];
+        const int r = rc >> 4, c = rc & 15;
+        const unsigned clt = (1u << c) - 1u;
+        double acc = 0.0;
+        for (int p = p0; p < p1; ++p) {
+            const int a = pairs_a[p], b = pairs_b[p];
+            const unsigned am = a_masks[16 * (size_t)a + r];
+            unsigned m = am & b_masks_t[16 * (size_t)b + c];
+            if (!m) continue;
+            const double *av = a_vals + a_nnz_ptr[a] + a_rowptr[16 * (size_t)a + r];
+            const double *bvbase = b_vals + b_nnz_ptr[b];
+            while (m) {
+                const int kk = __builtin_ctz(m);
+                m &= m - 1;
+                const int ao = __popc(am & ((1u << kk) - 1u));
+                const int bo = __popc((unsigned)b_masks[16 * (size_t)b + kk] & clt);
+                acc = __builtin_fma(av[ao], bvbase[b_rowptr[16 * (size_t)b + kk] + bo], acc);
+            }
+        }
+        c_vals[off + n] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a14 export: tiled C -> CSR without the reference's 16-byte-record stable_sort
+// (spgemm.cu:1516-1519): C tiles are already sorted by (tile row, tile col) and entries are
+// row-major inside a tile, so row R = 16 i + r is the concatenation over the tiles of tile row
+// i of that tile's row-r entries.  16 lanes per tile row, lane = r.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ex_rowcount_kernel(const int *__restrict__ c_tile_rowptr, const uint16_t *__restrict__ c_mask16,
+                                                          int mt, int nrows, int *__restrict__ rowcnt)
+{
+    int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    int r = threadIdx.x & 15;
+    if (i >= mt) return;
+    int cnt = 0;
+    for (int t = c_tile_rowptr[i]; t < c_tile_rowptr[i + 1]; ++t) cnt += __popc((unsigned)c_mask16[16 * (size_t)t + (r ^ 1)]);
+    int row = 16 * i + r;
+    if (row < nrows) rowcnt[row] = cnt;
+}
+
+__global__ void __launch_bounds__(256) ex_fill_kernel(const int *__restrict__ c_tile_rowptr, const int *__restrict__ c_tile_colidx,
+                                                      const uint16_t *__restrict__ c_mask16, const int *__restrict__ c_tile_nnz_ptr,
+                                                      const uint8_t *__restrict__ c_rowptr, const double *__restrict__ c_vals, int mt,
+                                                      int nrows, const int *__restrict__ rowptr, int *__restrict__ colidx,
+                                                      double *__restrict__ vals)
+{
+    int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    int r = threadIdx.x & 15;
+    if (i >= mt) return;
+    int row = 16 * i + r;
+    if (row >= nrows) return;
+    int dst = rowptr[row];
+    for (int t = c_tile_rowptr[i]; t < c_tile_rowptr[i + 1]; ++t) {
+        unsigned m = c_mask16[16 * (size_t)t + (r ^ 1)];
+        if (!m) continue;
+        int src = c_tile_nnz_ptr[t] + c_rowptr[16 * (size_t)t + r];
+        int cbase = c_tile_colidx[t] << 4;
+        while (m) {
+            int c = __builtin_ctz(m);
+            m &= m - 1;
+            colidx[dst] = cbase + c;
+            vals[dst] = c_vals[src];
+            ++dst;
+            ++src;
+        }
+    }
+}
+
+// per tile row of A: tile-level intermediate products (work estimate for the row-block split)
+__global__ void split_rowprod_kernel(const int *__restrict__ a_tile_rowptr, const int *__restrict__ a_tile_colidx,
+                                     const int *__restrict__ b_tile_rowptr, int mt, long long *__restrict__ rowprod)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= mt) return;
+    long long s = 0;
+    for (int a = a_tile_rowptr[i]; a < a_tile_rowptr[i + 1]; ++a) {
+        int k = a_tile_colidx[a];
+        s += b_tile_rowptr[k + 1] - b_tile_rowptr[k];
+    }
+    rowprod[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// host drivers
+// ------------------------------------------------------------------------------------------
+extern "C" pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const pem_tiled *B, int32_t tr_lo, int32_t tr_hi, pem_cplan **out)
+{
+    if (!ctx || !A || !B || !out) return PEM_E_INVALID;
+    *out = nullptr;
+    if (A->cols != B->rows) {
+        set_error("pem_cplan_create: A is %d x %d but B is %d x %d", A->rows, A->cols, B->rows, B->cols);
+        return PEM_E_INVALID;
+    }
+    if (tr_hi < 0) tr_hi = A->tile_rows;
+    if (tr_lo < 0 || tr_lo > tr_hi || tr_hi > A->tile_rows) {
+        set_error("pem_cplan_create: tile-row range [%d, %d) outside [0, %d]", tr_lo, tr_hi, A->tile_rows);
+        return PEM_E_INVALID;
+    }
+    pem_cplan *p = new pem_cplan();
+    p->A = A;
+    p->B = B;
+    p->tr_lo = tr_lo;
+    p->tr_hi = tr_hi;
+    p->a_lo = A->h_tile_rowptr[(size_t)tr_lo];
+    p->a_hi = A->h_tile_rowptr[(size_t)tr_hi];
+    *out = p;
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_cplan_destroy(pem_ctx *ctx, pem_cplan *plan)
+{
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    delete plan;
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_cplan_get_info(const pem_cplan *p, pem_cplan_info *info)
+{
+    if (!p || !info) return PEM_E_INVALID;
+    info->tile_row_begin = p->tr_lo;
+    info->tile_row_end = p->tr_hi;
+    info->row_begin = p->tr_lo * 16;
+    info->row_end = p->tr_hi * 16 < p->A->rows ? p->tr_hi * 16 : p->A->rows;
+    info->ntiles_c = p->ntiles_c;
+    info->npairs = p->npairs;
+    info->nnz_c = p->nnz_c;
+    return PEM_OK;
+}
+
+static pem_status step_elapsed(pem_ctx *ctx, int e0, double *dst)
+{
+    float ms = 0.f;
+    PEM_HIP(hipEventElapsedTime(&ms, ctx->ev[e0], ctx->ev[e0 + 1]));
+    *dst = ms;
+    return PEM_OK;
+}
+
+static pem_status step1_impl(pem_ctx *ctx, pem_cplan *p)
+{
+    const pem_tiled *A = p->A, *B = p->B;
+    hipStream_t st = ctx->stream;
+    const int nA = p->a_hi - p->a_lo, mt = p->tr_hi - p->tr_lo;
+    const int bits_tc = bits_for((uint64_t)B->tile_cols), bits_row = bits_for((uint64_t)(mt > 0 ? mt : 1));
+    p->state = 0;
+    p->ntiles_c = p->npairs = p->nnz_c = 0;
+    PEM_TRY(zero_flags(ctx));
+    PEM_HIP(hipEventRecord(ctx->ev[0], st));
+    PEM_TRY(p->aprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
+    PEM_TRY(p->c_tile_rowptr.reserve(sizeof(int) * ((size_t)mt + 4)));
+    PEM_HIP(hipMemsetAsync(p->c_tile_rowptr.p, 0, sizeof(int) * ((size_t)mt + 1), st));
+    if (nA > 0)
+        PEM_LAUNCH(ctx, s1_aprod_kernel, grid_for((size_t)nA, 256), 256, A->tile_colidx.as<int>(), p->a_lo, nA, B->tile_rowptr.as<int>(),
+                   p->aprod_off.as<int>());
+    PEM_TRY(exclusive_scan_i32(ctx, p->aprod_off.as<int>(), p->aprod_off.as<int>(), (size_t)nA, ctx->d_scalars));
+    int64_t P = 0;
+    PEM_TRY(read_scalars(ctx, ctx->d_scalars, 1, &P));
+    if (P > 0x7FFFFFFFll) {
+        set_error("step 1: %lld tile pairs exceed the int32 range of the reference's pair arrays", (long long)P);
+        return PEM_E_OVERFLOW;
+    }
+    p->npairs = P;
+    const size_t n = (size_t)P;
+    PEM_TRY(p->pairs_offset.reserve(sizeof(int) * 4));
+    int64_t TC = 0;
+    if (n > 0) {
+        PEM_TRY(p->prod_a.reserve(sizeof(int) * n));
+        PEM_TRY(p->prod_b.reserve(sizeof(int) * n));
+        PEM_TRY(p->sk0.reserve(sizeof(uint64_t) * n));
+        PEM_TRY(p->sk1.reserve(sizeof(uint64_t) * n));
+        PEM_TRY(p->sv0.reserve(sizeof(uint32_t) * n));
+        PEM_TRY(p->sv1.reserve(sizeof(uint32_t) * n));
+        PEM_LAUNCH(ctx, s1_expand_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_keys.as<long long>(), p->a_lo, nA, p->aprod_off.as<int>(),
+                   B->tile_rowptr.as<int>(), B->tile_colidx.as<int>(), p->tr_lo, bits_tc, p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(),
+                   p->prod_a.as<int>(), p->prod_b.as<int>());
+        uint64_t *keys = nullptr;
+        PEM_TRY(radix_sort_u64_u32(ctx, p->sk0.as<uint64_t>(), p->sk1.as<uint64_t>(), p->sv0.as<uint32_t>(), p->sv1.as<uint32_t>(), n,
+                                   bits_tc + bits_row, &keys, &p->sorted_perm));
+        DevBuf &head = ctx->tmp[2];
+        PEM_TRY(head.reserve(sizeof(int) * (n + 4)));
+        PEM_LAUNCH(ctx, s1_heads_kernel, grid_for(n, 256), 256, keys, n, head.as<int>());
+        PEM_TRY(exclusive_scan_i32(ctx, head.as<int>(), head.as<int>(), n, ctx->d_scalars + 1));
+        PEM_TRY(read_scalars(ctx, ctx->d_scalars + 1, 1, &TC));
+        const size_t ntc = (size_t)TC;
+        PEM_TRY(p->c_tile_rowidx.reserve(sizeof(int) * (ntc + 4)));
+        PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
+        PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
+        PEM_LAUNCH(ctx, s1_emit_ctiles_kernel, grid_for(n, 256), 256, keys, head.as<int>(), n, p->tr_lo, bits_tc, p->c_tile_rowidx.as<int>(),
+                   p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>());
+        PEM_LAUNCH(ctx, s1_c_rowptr_kernel, grid_for(ntc, 256), 256, p->c_tile_rowidx.as<int>(), (long long)TC, p->tr_lo, mt,
+                   p->c_tile_rowptr.as<int>());
+    } else {
+        PEM_HIP(hipMemsetAsync(p->pairs_offset.p, 0, sizeof(int), st));
+    }
+    p->ntiles_c = TC;
+    PEM_HIP(hipEventRecord(ctx->ev[1], st));
+    p->state = 1;
+    return PEM_OK;
+}
+
+static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
+{
+    if (p->state < 1) {
+        set_error("pem_spgemm_step2 called before step 1");
+        return PEM_E_STATE;
+    }
+    const pem_tiled *A = p->A, *B = p->B;
+    hipStream_t st = ctx->stream;
+    const size_t n = (size_t)p->npairs, ntc = (size_t)p->ntiles_c;
+    PEM_HIP(hipEventRecord(ctx->ev[2], st));
+    PEM_TRY(p->pairs_a.reserve(sizeof(int) * (n + 4)));
+    PEM_TRY(p->pairs_b.reserve(sizeof(int) * (n + 4)));
+    PEM_TRY(p->c_mask.reserve(sizeof(uint32_t) * 8 * (ntc + 1)));
+    PEM_TRY(p->c_tile_nnz_ptr.reserve(sizeof(int) * (ntc + 4)));
+    PEM_TRY(p->c_rowptr.reserve(16 * (ntc + 1)));
+    if (n > 0)
+        PEM_LAUNCH(ctx, s2_pairs_kernel, grid_for(n, 256), 256, p->sorted_perm, p->prod_a.as<int>(), p->prod_b.as<int>(), n, p->pairs_a.as<int>(),
+                   p->pairs_b.as<int>());
+    if (ntc > 0)
+        PEM_LAUNCH(ctx, s2_cmask_kernel, grid_for(ntc * 16, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
+                   (long long)ntc, A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>());
+    PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_nnz_ptr.as<int>(), p->c_tile_nnz_ptr.as<int>(), ntc, ctx->d_scalars + 2));
+    int64_t nnzc = 0;
+    PEM_TRY(read_scalars(ctx, ctx->d_scalars + 2, 1, &nnzc));
+    if (nnzc > 0x7FFFFFFFll) {
+        set_error("step 2: C has %lld nonzeros, beyond the int32 range of the reference's offsets", (long long)nnzc);
+        return PEM_E_OVERFLOW;
+    }
+    p->nnz_c = nnzc;
+    PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
+    PEM_TRY(p->c_vals.reserve(sizeof(double) * ((size_t)nnzc + 1)));
+    if (ntc > 0)
+        PEM_LAUNCH(ctx, s2_crowcol_kernel, grid_for(ntc * 16, 256), 256, p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
+                   p->c_rowptr.as<uint8_t>(), p->c_rowcolidx.as<uint8_t>());
+    PEM_HIP(hipEventRecord(ctx->ev[3], st));
+    p->state = 2;
+    return PEM_OK;
+}
+
+static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
+{
+    if (p->state < 2) {
+        set_error("pem_spgemm_step3 called before step 2");
+        return PEM_E_STATE;
+    }
+    const pem_tiled *A = p->A, *B = p->B;
+    hipStream_t st = ctx->stream;
+    const size_t ntc = (size_t)p->ntiles_c;
+    PEM_HIP(hipEventRecord(ctx->ev[4], st));
+    if (ntc > 0)
+        PEM_LAUNCH(ctx, s3_accumulate_kernel, grid_for(ntc * 16, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
+                   (long long)ntc, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<double>(), A->tile_nnz_ptr.as<int>(),
+                   A->vals.as<double>(), A->masks.as<uint16_t>(), A->rowptr.as<uint8_t>(), B->tile_nnz_ptr.as<int>(), B->vals.as<double>(),
+                   B->masks.as<uint16_t>(), B->rowptr.as<uint8_t>(), B->masks_t.as<uint16_t>());
+    PEM_HIP(hipEventRecord(ctx->ev[5], st));
+    p->state = 3;
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_spgemm_step1(pem_ctx *ctx, pem_cplan *plan)
+{
+    if (!ctx || !plan) return PEM_E_INVALID;
+    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_TRY(step1_impl(ctx, plan));
+    PEM_HIP(hipStreamSynchronize(ctx->stream));
+    return step_elapsed(ctx, 0, &ctx->timings.step1_ms);
+}
+
+extern "C" pem_status pem_spgemm_step2(pem_ctx *ctx, pem_cplan *plan)
+{
+    if (!ctx || !plan) return PEM_E_INVALID;
+    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_TRY(step2_impl(ctx, plan));
+    PEM_HIP(hipStreamSynchronize(ctx->stream));
+    return step_elapsed(ctx, 2, &ctx->timings.step2_ms);
+}
+
+extern "C" pem_status pem_spgemm_step3(pem_ctx *ctx, pem_cplan *plan)
+{
+    if (!ctx || !plan) return PEM_E_INVALID;
+    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_TRY(step3_impl(ctx, plan));
+    PEM_HIP(hipStreamSynchronize(ctx->stream));
+    return step_elapsed(ctx, 4, &ctx->timings.step3_ms);
+}
+
+// one iteration of the reference's timed loop (spgemm.cu:1136-1341): wall clock around
+// step1+step2+step3 including every allocation and size read-back, ended by a device sync.
+extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
+{
+    if (!ctx || !plan) return PEM_E_INVALID;
+    PEM_HIP(hipSetDevice(ctx->device));
+    auto t0 = std::chrono::high_resolution_clock::now();
+    PEM_TRY(step1_impl(ctx, plan));
+    PEM_TRY(step2_impl(ctx, plan));
+    PEM_TRY(step3_impl(ctx, plan));
+    PEM_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->timings.spgemm_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    PEM_TRY(step_elapsed(ctx, 0, &ctx->timings.step1_ms));
+    PEM_TRY(step_elapsed(ctx, 2, &ctx->timings.step2_ms));
+    PEM_TRY(step_elapsed(ctx, 4, &ctx->timings.step3_ms));
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_cplan_get_array(pem_ctx *ctx, const pem_cplan *p, pem_cplan_array which, void *host_dst, int64_t bytes)
+{
+    if (!ctx || !p || (!host_dst && bytes > 0)) return PEM_E_INVALID;
+    const size_t TC = (size_t)p->ntiles_c, P = (size_t)p->npairs, NZ = (size_t)p->nnz_c, mt = (size_t)(p->tr_hi - p->tr_lo);
+    const void *src = nullptr;
+    size_t want = 0;
+    int need = 1;
+    switch (which) {
+    case PEM_C_TILE_ROWPTR: src = p->c_tile_rowptr.p; want = 4 * (mt + 1); break;
+    case PEM_C_TILE_ROWIDX: src = p->c_tile_rowidx.p; want = 4 * TC; break;
+    case PEM_C_TILE_COLIDX: src = p->c_tile_colidx.p; want = 4 * TC; break;
+    case PEM_C_PAIRS_OFFSET: src = p->pairs_offset.p; want = 4 * (TC + 1); break;
+    case PEM_C_PAIRS_A: src = p->pairs_a.p; want = 4 * P; need = 2; break;
+    case PEM_C_PAIRS_B: src = p->pairs_b.p; want = 4 * P; need = 2; break;
+    case PEM_C_MASK: src = p->c_mask.p; want = 32 * TC; need = 2; break;
+    case PEM_C_TILE_NNZ_PTR: src = p->c_tile_nnz_ptr.p; want = 4 * (TC + 1); need = 2; break;
+    case PEM_C_ROWPTR: src = p->c_rowptr.p; want = 16 * TC; need = 2; break;
+    case PEM_C_ROWCOLIDX: src = p->c_rowcolidx.p; want = NZ; need = 2; break;
+    case PEM_C_VALS: src = p->c_vals.p; want = 8 * NZ; need = 3; break;
+    default: set_error("unknown pem_cplan_array %d", (int)which); return PEM_E_INVALID;
+    }
+    if (p->state < need) {
+        set_error("pem_cplan_get_array(%d): step %d has not run", (int)which, need);
+        return PEM_E_STATE;
+    }
+    if ((size_t)bytes != want) {
+        set_error("pem_cplan_get_array(%d): caller passed %lld bytes, array has %zu", (int)which, (long long)bytes, want);
+        return PEM_E_INVALID;
+    }
+    if (want == 0) return PEM_OK;
+    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_HIP(hipMemcpyAsync(host_dst, src, want, hipMemcpyDeviceToHost, ctx->stream));
+    PEM_HIP(hipStreamSynchronize(ctx->stream));
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_c_export_csr_device(pem_ctx *ctx, const pem_cplan *p, int32_t *d_rowptr, int32_t *d_colidx, double *d_vals)
+{
+    if (!ctx || !p || !d_rowptr) return PEM_E_INVALID;
+    if (p->state < 3) {
+        set_error("pem_c_export_csr: step 3 has not run");
+        return PEM_E_STATE;
+    }
+    if (p->nnz_c > 0 && (!d_colidx || !d_vals)) return PEM_E_INVALID;
+    PEM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int mt = p->tr_hi - p->tr_lo;
+    const int r0 = p->tr_lo * 16, r1 = p->tr_hi * 16 < p->A->rows ? p->tr_hi * 16 : p->A->rows;
+    const int nrows = r1 - r0;
+    PEM_HIP(hipEventRecord(ctx->ev[6], st));
+    PEM_HIP(hipMemsetAsync(d_rowptr, 0, sizeof(int) * ((size_t)nrows + 1), st));
+    if (mt > 0 && nrows > 0) {
+        PEM_LAUNCH(ctx, ex_rowcount_kernel, grid_for((size_t)mt * 16, 256), 256, p->c_tile_rowptr.as<int>(), p->c_mask.as<uint16_t>(), mt, nrows,
+                   d_rowptr);
+        PEM_TRY(exclusive_scan_i32(ctx, d_rowptr, d_rowptr, (size_t)nrows, nullptr));
+        if (p->nnz_c > 0)
+            PEM_LAUNCH(ctx, ex_fill_kernel, grid_for((size_t)mt * 16, 256), 256, p->c_tile_rowptr.as<int>(), p->c_tile_colidx.as<int>(),
+                       p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>(), p->c_rowptr.as<uint8_t>(), p->c_vals.as<double>(), mt, nrows,
+                       d_rowptr, d_colidx, d_vals);
+    }
+    PEM_HIP(hipEventRecord(ctx->ev[7], st));
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_c_export_csr(pem_ctx *ctx, const pem_cplan *p, int64_t *nnz, int32_t *rowptr, int32_t *colidx, double *vals)
+{
+    if (!ctx || !p) return PEM_E_INVALID;
+    if (p->state < 3) {
+        set_error("pem_c_export_csr: step 3 has not run");
+        return PEM_E_STATE;
+    }
+    if (nnz) *nnz = p->nnz_c;
+    if (!rowptr) return PEM_OK;   // size query
+    PEM_HIP(hipSetDevice(ctx->device));
+    const int r0 = p->tr_lo * 16, r1 = p->tr_hi * 16 < p->A->rows ? p->tr_hi * 16 : p->A->rows;
+    const size_t nrows = (size_t)(r1 - r0), nz = (size_t)p->nnz_c;
+    DevBuf dR, dC, dV;
+    PEM_TRY(dR.reserve(sizeof(int) * (nrows + 4)));
+    PEM_TRY(dC.reserve(sizeof(int) * (nz + 4)));
+    PEM_TRY(dV.reserve(sizeof(double) * (nz + 1)));
+    PEM_TRY(pem_c_export_csr_device(ctx, p, dR.as<int>(), dC.as<int>(), dV.as<double>()));
+    PEM_HIP(hipMemcpyAsync(rowptr, dR.p, sizeof(int) * (nrows + 1), hipMemcpyDeviceToHost, ctx->stream));
+    if (nz) {
+        if (!colidx || !vals) return PEM_E_INVALID;
+        PEM_HIP(hipMemcpyAsync(colidx, dC.p, sizeof(int) * nz, hipMemcpyDeviceToHost, ctx->stream));
+        PEM_HIP(hipMemcpyAsync(vals, dV.p, sizeof(double) * nz, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PEM_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->timings.export_ms = ms;
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_c_export_coo(pem_ctx *ctx, const pem_cplan *p, int64_t *nnz, int32_t *rows, int32_t *cols, double *vals)
+{
+    if (!ctx || !p) return PEM_E_INVALID;
+    if (p->state < 3) {
+        set_error("pem_c_export_coo: step 3 has not run");
+        return PEM_E_STATE;
+    }
+    if (nnz) *nnz = p->nnz_c;
+    if (!rows) return PEM_OK;
+    const int r0 = p->tr_lo * 16, r1 = p->tr_hi * 16 < p->A->rows ? p->tr_hi * 16 : p->A->rows;
+    std::vector<int> rp((size_t)(r1 - r0) + 1);
+    PEM_TRY(pem_c_export_csr(ctx, p, nullptr, rp.data(), cols, vals));
+    for (int r = r0; r < r1; ++r)   // sorted (row, col) order = CSR order (spgemm.cu:1516-1519)
+        for (int e = rp[(size_t)(r - r0)]; e < rp[(size_t)(r - r0) + 1]; ++e) rows[e] = r;
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_split_tile_rows(pem_ctx *ctx, const pem_tiled *A, const pem_tiled *B, int nparts, int32_t *bounds)
+{
+    if (!ctx || !A || !B || !bounds || nparts < 1) return PEM_E_INVALID;
+    if (A->cols != B->rows) {
+        set_error("pem_split_tile_rows: inner dimensions differ");
+        return PEM_E_INVALID;
+    }
+    PEM_HIP(hipSetDevice(ctx->device));
+    const int mt = A->tile_rows;
+    DevBuf &rp = ctx->tmp[3];
+    PEM_TRY(rp.reserve(sizeof(long long) * ((size_t)mt + 1)));
+    PEM_LAUNCH(ctx, split_rowprod_kernel, grid_for((size_t)mt, 256), 256, A->tile_rowptr.as<int>(), A->tile_colidx.as<int>(),
+               B->tile_rowptr.as<int>(), mt, rp.as<long long>());
+    std::vector<long long> h((size_t)mt);
+    PEM_HIP(hipMemcpyAsync(h.data(), rp.p, sizeof(long long) * (size_t)mt, hipMemcpyDeviceToHost, ctx->stream));
+    PEM_HIP(hipStreamSynchronize(ctx->stream));
+    // weight = products + tiles of the row (so empty-product rows still spread out)
+    std::vector<double> pre((size_t)mt + 1, 0.0);
+    for (int i = 0; i < mt; ++i)
+        pre[(size_t)i + 1] = pre[(size_t)i] + (double)h[(size_t)i] + (double)(A->h_tile_rowptr[(size_t)i + 1] - A->h_tile_rowptr[(size_t)i]) + 1.0;
+    bounds[0] = 0;
+    int row = 0;
+    for (int g = 1; g < nparts; ++g) {
+        double target = pre[(size_t)mt] * (double)g / (double)nparts;
+        while (row < mt && pre[(size_t)row + 1] <= target) ++row;
+        bounds[g] = row;
+    }
+    bounds[nparts] = mt;
+    return PEM_OK;
+}

@@ -1,0 +1,65 @@
+"""Small seeded matrices for the parity tests (edge cases of SURVEY 8(c))."""
+import numpy as np
+
+
+def _vals(rng, n):
+    v = rng.uniform(-1.0, 1.0, n)
+    v[v == 0.0] = 0.25
+    return v
+
+
+def random_coo(rng, rows, cols, nnz):
+    key = rng.choice(rows * cols, size=min(nnz, rows * cols), replace=False)
+    key = rng.permutation(key)
+    return rows, cols, (key // cols).astype(np.int32), (key % cols).astype(np.int32), _vals(rng, len(key))
+
+
+def cases():
+    """name -> (rows, cols, I, J, V, transpose_B)"""
+    rng = np.random.default_rng(12345)
+    out = {}
+    out["tiny_9x9"] = random_coo(rng, 9, 9, 49) + (False,)
+    out["one_entry"] = (5, 5, np.array([3], np.int32), np.array([3], np.int32), np.array([2.5]), False)
+    out["rand_50"] = random_coo(rng, 50, 50, 240) + (False,)
+    out["rand_300"] = random_coo(rng, 300, 300, 1800) + (False,)
+    out["rect_70x40_AAt"] = random_coo(rng, 70, 40, 230) + (True,)
+    out["rect_33x65_AAt"] = random_coo(rng, 33, 65, 400) + (True,)
+    # rows >= last multiple of 16, size not a multiple of 16
+    out["ragged_37"] = random_coo(rng, 37, 37, 300) + (False,)
+    # a fully dense 16x16 tile: 256 nnz, u8 rowPtr max 240, slot 255
+    I, J = np.meshgrid(np.arange(16), np.arange(16), indexing="ij")
+    out["dense_tile"] = (16, 16, I.ravel().astype(np.int32), J.ravel().astype(np.int32), _vals(rng, 256), False)
+    # dense 48x48 (9 dense tiles, every C tile dense, 3 pairs each)
+    I, J = np.meshgrid(np.arange(48), np.arange(48), indexing="ij")
+    p = rng.permutation(48 * 48)
+    out["dense_48"] = (48, 48, I.ravel()[p].astype(np.int32), J.ravel()[p].astype(np.int32), _vals(rng, 48 * 48), False)
+    # empty rows / empty tile rows / empty matrix
+    r, c, I, J, V = random_coo(rng, 200, 200, 500)
+    keep = (I < 40) | (I >= 120)
+    out["empty_rows"] = (200, 200, I[keep], J[keep], V[keep], False)
+    out["empty_matrix"] = (40, 40, np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0), False)
+    # 1 x N and N x 1 shapes (A*A^T and A^T-like products)
+    out["row_vector_AAt"] = (1, 100, np.zeros(30, np.int32), rng.choice(100, 30, replace=False).astype(np.int32), _vals(rng, 30), True)
+    out["col_vector_AAt"] = (100, 1, rng.choice(100, 30, replace=False).astype(np.int32), np.zeros(30, np.int32), _vals(rng, 30), True)
+    # explicit zero values and numerically cancelling products (entries must stay)
+    I = np.array([0, 0, 1, 2, 1], np.int32)
+    J = np.array([1, 2, 0, 0, 1], np.int32)
+    V = np.array([1.0, 1.0, 3.0, -3.0, 0.0])
+    out["cancel_and_zero"] = (3, 3, I, J, V, False)
+    # power-law rows (webbase-like), banded (mc2depi-like), diagonal
+    n = 600
+    deg = np.minimum((rng.pareto(1.2, n) + 1).astype(int), 200)
+    I = np.repeat(np.arange(n), deg)
+    J = rng.integers(0, n, len(I))
+    key = np.unique(I.astype(np.int64) * n + J)
+    key = rng.permutation(key)
+    out["powerlaw_600"] = (n, n, (key // n).astype(np.int32), (key % n).astype(np.int32), _vals(rng, len(key)), False)
+    i = np.arange(500)
+    I = np.concatenate([i, i[1:], i[:-1], i[:-22]])
+    J = np.concatenate([i, i[1:] - 1, i[:-1] + 1, i[:-22] + 22])
+    p = rng.permutation(len(I))
+    out["banded_500_AAt"] = (500, 500, I[p].astype(np.int32), J[p].astype(np.int32), _vals(rng, len(I)), True)
+    out["diag_100"] = (100, 100, np.arange(100, dtype=np.int32), np.arange(100, dtype=np.int32), _vals(rng, 100), False)
+    # wide: more than 16384 tile columns (the reference's step-1 dispatch boundary, spgemm.cu:1142)
+    out["wide_tilecols"] = random_coo(rng, 16385 * 16, 64, 900) + (True,)
+    return out
