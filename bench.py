@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X: SpGEMM GFLOP/s = 2*flop / t, where t is
+one pass of step1+step2+step3 (spgemm.cu:1136-1341, 1403) on a matrix already resident in
+HBM in tiled form.  `python bench.py --gpus N --steps K --warmup W`; for N>1 launch through
+torch.distributed.run (one rank per GPU, RCCL): A is split by tile rows, B replicated, and the
+CSR slices of C are gathered to rank 0 inside every timed step (the path's one exchange step).
+
+Prints ONE JSON line on rank 0 (driver contract) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def kernel_alg_bytes(name, d):
+    """Compulsory HBM bytes of ONE launch of a hot-path kernel: every distinct byte it must read
+    once plus every byte it must write once (DESIGN.md 'Kernels and rooflines').  d: sizes."""
+    P, TC, NZ = d["npairs"], d["ntiles_c"], d["nnz_c"]
+    nA, nB, TA, TB = d["nnz_a"], d["nnz_b"], d["ntiles_a"], d["ntiles_b"]
+    table = {
+        "rs_hist_kernel": 8 * P,
+        "rs_scatter_kernel": 24 * P,
+        "s1_expand_kernel": 20 * P + 8 * TA + 4 * TB,
+        "s1_heads_kernel": 12 * P,
+        "s1_emit_ctiles_kernel": 12 * P + 12 * TC,
+        "s2_pairs_kernel": 20 * P,
+        "s2_cmask_kernel": 8 * P + 32 * TA + 32 * TB + 36 * TC,
+        "s2_crowcol_kernel": 36 * TC + 16 * TC + NZ,
+        "s3_accumulate_kernel": 8 * P + 8 * TC + NZ + (8 * nA + 52 * TA) + (8 * nB + 84 * TB) + 8 * NZ,
+        "s12_row_kernel": 8 * P + 8 * TA + 8 * TB + 12 * TC,
+    }
+    return table.get(name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)     # REPEAT=10 (reference Makefile:34)
+    ap.add_argument("--warmup", type=int, default=2)     # reference WARMUP=1 (spgemm.cu:712-714)
+    ap.add_argument("--workload", default="webbase-1M", choices=["cage4", "scircuit", "webbase-1M", "mc2depi", "cage15"])
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the stand-in (tests only; 1.0 = BASELINE size)")
+    ap.add_argument("--aat", action="store_true", help="C = A*A^T instead of A^2 (default for mc2depi)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: leave the C slices on their ranks")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the product path has no CPU fallback", file=sys.stderr)
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = graft.load_package()
+    standins = importlib.import_module("pem_spgemm_amd.standins")
+    mg = importlib.import_module("pem_spgemm_amd.multigpu")
+
+    aat = args.aat or args.workload == "mc2depi"
+    t_gen = time.perf_counter()
+    rows, cols, I, J, V = standins.make(args.workload, args.scale)
+    t_gen = time.perf_counter() - t_gen
+
+    # inputs resident in HBM before anything is timed
+    dI, dJ, dV = torch.from_numpy(I).to(dev), torch.from_numpy(J).to(dev), torch.from_numpy(V).to(dev)
+    torch.cuda.synchronize()
+    ctx = pkg.Context(local_rank)
+    A = pkg.Tiled.from_coo_device(ctx, rows, cols, len(I), dI.data_ptr(), dJ.data_ptr(), dV.data_ptr(), False)
+    B = pkg.Tiled.from_coo_device(ctx, rows, cols, len(I), dI.data_ptr(), dJ.data_ptr(), dV.data_ptr(), True) if aat else A
+    del dI, dJ, dV
+    flop = pkg.flop_count(ctx, A, B)
+    bounds = pkg.split_tile_rows(ctx, A, B, world)
+    lo, hi = mg.slice_bounds(bounds, rank)
+    plan = pkg.CPlan(ctx, A, B, lo, hi)
+
+    gather = world > 1 and not args.no_gather
+    bufs = {}
+
+    def step():
+        plan.spgemm()
+        if gather:
+            info = plan.info()
+            nrows, nz = info["row_end"] - info["row_begin"], info["nnz_c"]
+            if bufs.get("nz") != nz:
+                bufs.update(nz=nz, rp=torch.empty(nrows + 1, dtype=torch.int32, device=dev),
+                            ci=torch.empty(max(nz, 1), dtype=torch.int32, device=dev),
+                            v=torch.empty(max(nz, 1), dtype=torch.float64, device=dev))
+            plan.export_csr_device(bufs["rp"].data_ptr(), bufs["ci"].data_ptr(), bufs["v"].data_ptr())
+            ctx.synchronize()
+            bufs["out"] = mg.gather_csr_slices(bufs["rp"], bufs["ci"][:nz], bufs["v"][:nz], dst=0)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    ms_per_step = elapsed * 1e3 / max(args.steps, 1)
+    tm = ctx.timings()
+    info = plan.info()
+
+    # per-kernel device time, measured live with HIP events on the library's stream (separate
+    # pass so the two event records per launch stay out of the timed region above)
+    ctx.set_kernel_profiling(True)
+    ctx.reset_kernel_stats()
+    nprof = max(1, min(args.steps, 3))
+    for _ in range(nprof):
+        plan.spgemm()
+    stats = ctx.kernel_stats()
+    ctx.set_kernel_profiling(False)
+    dims = dict(npairs=info["npairs"], ntiles_c=info["ntiles_c"], nnz_c=info["nnz_c"], nnz_a=A.nnz, nnz_b=B.nnz,
+                ntiles_a=A.ntiles, ntiles_b=B.ntiles)
+    kern = {k: dict(calls_per_step=v["calls"] / nprof, avg_ms=v["total_ms"] / max(v["calls"], 1), ms_per_step=v["total_ms"] / nprof)
+            for k, v in stats.items()}
+    dom = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
+    roofline = None
+    if dom is not None:
+        ab = kernel_alg_bytes(dom, dims)
+        ach = (ab / (kern[dom]["avg_ms"] * 1e-3) / 1e9) if ab else None
+        roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS) if ach else None,
+                        traffic=None, alg_bytes_per_launch=ab, avg_launch_ms=kern[dom]["avg_ms"],
+                        launches_per_step=kern[dom]["calls_per_step"])
+
+    # whole-pipeline figure against SURVEY 8(d)'s B_alg (this rank's slice at N>1)
+    nrows_c = info["row_end"] - info["row_begin"]
+    b_alg = 12 * (A.nnz + B.nnz + info["nnz_c"]) + 4 * (A.rows + 1) + 4 * (B.rows + 1) + 4 * (nrows_c + 1)
+    t_kernel_ms = tm["step1_ms"] + tm["step2_ms"] + tm["step3_ms"]
+
+    total_nnz_c, total_tc, total_p = info["nnz_c"], info["ntiles_c"], info["npairs"]
+    if dist is not None:
+        tt = torch.tensor([info["nnz_c"], info["ntiles_c"], info["npairs"]], dtype=torch.int64, device=dev)
+        dist.all_reduce(tt)
+        total_nnz_c, total_tc, total_p = [int(x) for x in tt.tolist()]
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU port (oracle/ref_serial_csr.c: the reference has no CPU SpGEMM path) on this box's
+        # host cores -- a reported baseline beside the GPU number, never the thing measured above.
+        o = graft.load_oracle()
+        threads = o.max_threads()
+        oa = o.Csr(rows, cols, I, J, V, False)
+        ob = o.Csr(rows, cols, I, J, V, True) if aat else oa
+        t1 = time.perf_counter()
+        oc = o.csr_spgemm(oa, ob, threads)
+        tc = time.perf_counter() - t1
+        assert oc.nnz == total_nnz_c, f"CPU port C nnz {oc.nnz} != GPU {total_nnz_c}"
+        cpu_baseline = dict(value=2.0 * flop / tc / 1e9, unit="GFLOP/s", cores=threads, kind="port",
+                            sample=f"full {args.workload} stand-in, 1 run of the OpenMP row-parallel Gustavson CSR port ({tc * 1e3:.0f} ms)",
+                            ms=tc * 1e3)
+
+    if rank == 0:
+        out = {
+            "metric": "SpGEMM GFLOP/s (2*flop / t(step1+step2+step3))",
+            "value": 2.0 * flop / (ms_per_step * 1e-3) / 1e9,
+            "unit": "GFLOP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload} stand-in (seeded synthetic, scale {args.scale}) {'A*A^T' if aat else 'A^2'}",
+                       "rows": rows, "cols": cols, "nnz": int(len(I)), "flop": int(flop), "C_nnz": total_nnz_c, "C_tiles": total_tc,
+                       "tile_pairs": total_p, "A_tiles": int(A.ntiles), "compression_ratio": flop / max(total_nnz_c, 1),
+                       "parallelism": f"rowblock{world}" + ("+gather" if gather else "")},
+            "roofline": roofline,
+            "roofline_pipeline": {"bound": "hbm", "B_alg_bytes": b_alg, "t_kernel_ms": t_kernel_ms,
+                                  "achieved": b_alg / (t_kernel_ms * 1e-3) / 1e9 if t_kernel_ms > 0 else None, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": b_alg / (t_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if t_kernel_ms > 0 else None,
+                                  "note": "rank 0 slice: 12*(nnzA+nnzB+nnzC)+4*(rows+1)*3 over the hipEvent spans of step1+2+3"},
+            "cpu_baseline": cpu_baseline,
+            "steps_ms": {"step1": tm["step1_ms"], "step2": tm["step2_ms"], "step3": tm["step3_ms"], "wall_last": tm["spgemm_wall_ms"]},
+            "conversion_ms": {"A": A.conv_ms, "A_tile_kernels": A.conv_tile_kernel_ms},
+            "kernels": kern,
+            "gen_s": t_gen,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

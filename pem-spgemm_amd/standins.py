@@ -26,16 +26,13 @@ def _values(rng, n):
 
 
 def _finish(rng, rows, cols, I, J, nnz):
-    """dedupe (i, j), trim or top up to exactly nnz entries, attach values, shuffle to 'file order'"""
-    key = I.astype(np.int64) * cols + J.astype(np.int64)
-    key = np.unique(key)
-    if len(key) > nnz:
-        key = rng.choice(key, size=nnz, replace=False)
-    while len(key) < nnz:   # top up with uniform entries (rare)
+    """dedupe (i, j), trim (or, rarely, top up) to exactly nnz entries, attach values, shuffle to 'file order'"""
+    key = np.unique(I.astype(np.int64) * cols + J.astype(np.int64))
+    while len(key) < nnz:   # top up with uniform entries (only when the structured draw fell short)
         extra = rng.integers(0, rows, 2 * (nnz - len(key))).astype(np.int64) * cols + rng.integers(0, cols, 2 * (nnz - len(key)))
         key = np.unique(np.concatenate([key, extra]))
-        if len(key) > nnz:
-            key = rng.choice(key, size=nnz, replace=False)
+    if len(key) > nnz:
+        key = rng.choice(key, size=nnz, replace=False)
     key = rng.permutation(key)
     I = (key // cols).astype(np.int32)
     J = (key % cols).astype(np.int32)
@@ -79,19 +76,19 @@ def scircuit(seed=SEEDS["scircuit"], scale=1.0):
 
 
 def webbase(seed=SEEDS["webbase-1M"], scale=1.0):
-    """web-graph-like: power-law out-degree (alpha 2.1, max 4700); 70 % of links stay inside the
-    page's neighbourhood (+-48 rows: same host), 30 % go to globally popular pages whose
-    popularity follows the out-degree (hubs link to hubs)."""
+    """web-graph-like: power-law out-degree (alpha 2.1, max 4700); 90 % of a page's links stay in
+    its neighbourhood (+-max(24, out-degree) rows: same host), 10 % go to globally popular pages
+    whose popularity follows the out-degree (hubs link to hubs)."""
     n0, _, nnz0 = SIZES["webbase-1M"]
     n, nnz = max(64, int(n0 * scale)), max(128, int(nnz0 * scale))
     rng = np.random.default_rng(seed)
-    deg = _powerlaw_degrees(rng, n, int(nnz * 1.06), 2.1, min(4700, n // 2), 1)
+    deg = _powerlaw_degrees(rng, n, int(nnz * 1.25), 2.1, min(4700, n // 2), 1)
     rows = np.repeat(np.arange(n, dtype=np.int64), deg)
     m = len(rows)
-    local = rng.random(m) < 0.7
-    # global targets: sample proportional to out-degree (endpoint of a random existing link)
-    glob = rows[rng.integers(0, m, m)]
-    cols = np.where(local, rows + rng.integers(-48, 49, m), glob)
+    local = rng.random(m) < 0.9
+    w = np.maximum(24, np.repeat(deg, deg))
+    glob = rows[rng.integers(0, m, m)]   # endpoint of a random existing link: degree-proportional
+    cols = np.where(local, rows + np.floor((rng.random(m) * 2.0 - 1.0) * (w + 1)).astype(np.int64), glob)
     cols = np.clip(cols, 0, n - 1)
     return _finish(rng, n, n, rows, cols, nnz)
 
