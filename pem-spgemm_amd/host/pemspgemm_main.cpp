@@ -1,0 +1,165 @@
+// pemspgemm -- command-line front end with the reference's surface (spgemm.cu:720-1568):
+//     pemspgemm <matrix.mtx> [0|1] [any third argument => C = A*A^T]
+// reads one Matrix-Market file, forms C = A*A (or A*A^T), times WARMUP + REPEAT passes of
+// step1+step2+step3, prints the reference's report, appends the reference's 14 CSV columns
+// to ./pemspgemm_benchmark_result.csv and, when the 2nd argument is non-zero, writes the
+// sorted COO result to /tmp/SPGEMM_RESULT_{NNZ,ROWS,COLS,VALS}.txt.
+// Host C++ over the C ABI of libpemspgemm_hip.so; no HIP calls in this file.
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/pem_host.h"
+#include "../../include/pem_spgemm.h"
+
+static int env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return s && *s ? atoi(s) : dflt;
+}
+
+#define CHECK(expr)                                                              \
+    do {                                                                         \
+        pem_status _s = (expr);                                                  \
+        if (_s != PEM_OK) {                                                      \
+            fprintf(stderr, "pemspgemm: %s failed (%d): %s\n", #expr, _s, pem_last_error()); \
+            return 2;                                                            \
+        }                                                                        \
+    } while (0)
+
+int main(int argc, char *argv[])
+{
+    if (argc <= 1 || argc > 4) {   // spgemm.cu:722-725
+        printf("Provide a matrix market file path. Exiting.\n");
+        return 1;
+    }
+    const int WARMUP = env_int("PEM_WARMUP", 1);    // spgemm.cu:712-714
+    const int REPEAT = env_int("PEM_REPEAT", 10);   // reference Makefile:34 (-DREPEAT=10)
+    const bool fastest = env_int("PEM_FASTEST", 0) != 0;   // spgemm.cu:1359-1363
+    const bool save = argc >= 3 && atoi(argv[2]) != 0;     // spgemm.cu:1485 (the reference dereferences argv[2] unconditionally)
+    const bool aat = argc == 4;                            // spgemm.cu:788: presence of a 3rd argument, value ignored
+
+    auto conv_start = std::chrono::high_resolution_clock::now();   // spgemm.cu:760: the clock starts before the file is read
+    pem_coo m;
+    if (pem_mm_read(argv[1], 0, &m) != 0) {
+        fprintf(stderr, "pemspgemm: %s\n", pem_host_last_error());
+        return 1;
+    }
+    if (m.rows != m.cols && !aat) {   // spgemm.cu:782-786
+        printf("input is rectangular. Only AAt is possible. Exiting.\n");
+        return 1;
+    }
+    const int b_rows = aat ? m.cols : m.rows, b_cols = aat ? m.rows : m.cols;
+    printf("MATRIX A\nfilepath: %s\nRows: %d\nCols: %d\nNnz: %lld\n", argv[1], m.rows, m.cols, (long long)m.nnz);   // spgemm.cu:794-806
+    printf("MATRIX B\nfilepath: %s\nRows: %d\nCols: %d\nNnz: %lld\n", argv[1], b_rows, b_cols, (long long)m.nnz);
+
+    pem_ctx *ctx = nullptr;
+    CHECK(pem_ctx_create(env_int("PEM_DEVICE", 0), &ctx));
+    pem_tiled *A = nullptr, *B = nullptr;
+    CHECK(pem_tiled_from_coo(ctx, m.rows, m.cols, m.nnz, m.I, m.J, m.V, 0, &A));
+    if (aat)
+        CHECK(pem_tiled_from_coo(ctx, m.rows, m.cols, m.nnz, m.I, m.J, m.V, 1, &B));
+    else
+        B = A;   // the reference converts the same file twice (spgemm.cu:778-779); one tiling serves both roles here
+    const double conv_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - conv_start).count();
+    pem_tiled_info ia, ib;
+    CHECK(pem_tiled_get_info(A, &ia));
+    CHECK(pem_tiled_get_info(B, &ib));
+    uint64_t flop = 0;
+    CHECK(pem_flop_count(ctx, A, B, &flop));   // spgemm.cu:1068-1079
+
+    pem_cplan *plan = nullptr;
+    CHECK(pem_cplan_create(ctx, A, B, 0, -1, &plan));
+    std::vector<double> s1, s2, s3, wall;
+    for (int n = 0; n < WARMUP + REPEAT; ++n) {   // spgemm.cu:1133-1357
+        if (n == 0) printf("\nstep1 pemSpGEMM (tile-level expand + radix sort)\n\nstep2 pemSpGEMM\n\nstep3 pemSpGEMM\n\n\n");
+        CHECK(pem_spgemm(ctx, plan));
+        pem_timings t;
+        CHECK(pem_get_timings(ctx, &t));
+        if (n >= WARMUP) {
+            s1.push_back(t.step1_ms);
+            s2.push_back(t.step2_ms);
+            s3.push_back(t.step3_ms);
+            wall.push_back(t.spgemm_wall_ms);
+        }
+    }
+    auto pick = [&](const std::vector<double> &v, size_t idx) {
+        if (v.empty()) return 0.0;
+        if (fastest) return v[idx];
+        double s = 0;
+        for (double x : v) s += x;
+        return s / (double)v.size();
+    };
+    size_t fidx = 0;
+    if (fastest && !wall.empty()) {
+        fidx = (size_t)(std::min_element(wall.begin(), wall.end()) - wall.begin());
+        printf("fidx: %zu\n\n", fidx);
+    } else {
+        printf("warm up %d time\naverage over %d iterations\n\n", WARMUP, REPEAT);
+    }
+    const double step1 = pick(s1, fidx), step2 = pick(s2, fidx), step3 = pick(s3, fidx), total = pick(wall, fidx);
+    const double kernel = step1 + step2 + step3, malloc_ms = total - kernel;   // spgemm.cu:1353-1354
+    pem_cplan_info ci;
+    CHECK(pem_cplan_get_info(plan, &ci));
+    const double gflops = total > 0 ? (double)flop * 2.0 / (total * 1e6) : 0.0;   // spgemm.cu:1403
+    const double ratio = ci.nnz_c ? (double)flop / (double)ci.nnz_c : 0.0;       // spgemm.cu:1404
+
+    printf("<---Program done--->\n");   // spgemm.cu:1406-1422
+    printf("Matrix A CSR to tile kernel took---------%.2fms\n", ia.conv_tile_kernel_ms);
+    printf("Matrix B CSR to tile kernel took---------%.2fms\n", ib.conv_tile_kernel_ms);
+    printf("total conversion overhead----------------%.2fms\n\n", conv_ms);
+    printf("step1 - High Level Multiplication took---%.2fms\n", step1);
+    printf("step2 - Allocating C took----------------%.2fms\n", step2);
+    printf("step3 - Accumulation took----------------%.2fms\n\n", step3);
+    printf("pemSpGEMM took %.2fms ----- GFlops: %.2f\nKernel time %.2fms\nmalloc time %.2fms\n", total, gflops, kernel, malloc_ms);
+    printf("Flop count: %llu\n\n", (unsigned long long)flop);
+    printf("C tiles: %lld\n", (long long)ci.ntiles_c);
+    printf("C nnz: %lld\n", (long long)ci.nnz_c);
+    printf("Compression ratio %.2f\n", ratio);
+    // roofline bookkeeping
+    const double b_alg = 12.0 * ((double)ia.nnz + (double)ib.nnz + (double)ci.nnz_c) + 4.0 * ((double)ia.rows + 1) + 4.0 * ((double)ib.rows + 1) +
+                         4.0 * ((double)ia.rows + 1);
+    const double frac_kernel = kernel > 0 ? b_alg / (kernel * 1e-3) / 8.0e12 : 0.0, frac_total = total > 0 ? b_alg / (total * 1e-3) / 8.0e12 : 0.0;
+    printf("B_alg %.0f bytes; HBM roofline fraction (8 TB/s): kernel %.4f, total %.4f\n", b_alg, frac_kernel, frac_total);
+
+    // CSV (spgemm.cu:1424-1450); matrix name = file stem (the reference's regex needs a '/' in the path)
+    std::string path = argv[1];
+    size_t slash = path.find_last_of('/');
+    std::string stem = slash == std::string::npos ? path : path.substr(slash + 1);
+    if (stem.size() > 4 && stem.compare(stem.size() - 4, 4, ".mtx") == 0) stem.resize(stem.size() - 4);
+    pem_csv_record rec = {stem.c_str(), flop, ci.nnz_c, ratio, ia.conv_tile_kernel_ms, ib.conv_tile_kernel_ms, conv_ms,
+                          step1, step2, step3, total, kernel, malloc_ms, gflops};
+    char extra[256];
+    snprintf(extra, sizeof extra, "1,%.0f,%.4f,%.4f,%lld,%lld", b_alg, frac_kernel, frac_total, (long long)ci.ntiles_c, (long long)ci.npairs);
+    const char *csv = getenv("PEM_CSV") ? getenv("PEM_CSV") : "./pemspgemm_benchmark_result.csv";
+    if (pem_csv_append(csv, &rec, extra) != 0) fprintf(stderr, "pemspgemm: %s\n", pem_host_last_error());
+
+    int rc = 0;
+    if (!save) {
+        printf("Not saving results. Exiting.\n");   // spgemm.cu:1487
+    } else {
+        const char *dir = getenv("PEM_RESULT_DIR") ? getenv("PEM_RESULT_DIR") : "/tmp";
+        std::vector<int32_t> rows((size_t)ci.nnz_c), cols((size_t)ci.nnz_c);
+        std::vector<double> vals((size_t)ci.nnz_c);
+        int64_t nnz = 0;
+        CHECK(pem_c_export_coo(ctx, plan, &nnz, rows.data(), cols.data(), vals.data()));   // spgemm.cu:1493-1543
+        pem_timings t;
+        CHECK(pem_get_timings(ctx, &t));
+        printf("sanitize_C took %.2fms\n", t.export_ms);
+        printf("Saving results to %s/SPGEMM_RESULT_*.txt\n", dir);
+        if (pem_write_result_files(dir, nnz, rows.data(), cols.data(), vals.data()) != 0) {
+            fprintf(stderr, "pemspgemm: %s\n", pem_host_last_error());
+            rc = 2;
+        }
+    }
+    printf("CLEANING UP RESOURCES\n\n");
+    pem_cplan_destroy(ctx, plan);
+    if (B != A) pem_tiled_destroy(ctx, B);
+    pem_tiled_destroy(ctx, A);
+    pem_ctx_destroy(ctx);
+    pem_coo_free(&m);
+    return rc;
+}

@@ -1,0 +1,75 @@
+"""CPU: the pemspgemm tool's host I/O (libpemhost.so) -- Matrix-Market reader against scipy.io
+fixtures and the oracle reader; result-file and CSV formats against spgemm.cu:1424-1450, 1527-1560."""
+import glob
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+MM = sorted(p for p in glob.glob(os.path.join(GOLD, "mm_*.mtx")) if os.path.exists(p[:-4] + ".npz"))
+
+
+@pytest.fixture(scope="module")
+def hostio(pkg):
+    return importlib.import_module("pem_spgemm_amd.hostio")
+
+
+def _sorted(m):
+    order = np.lexsort((m["J"], m["I"]))
+    return m["I"][order], m["J"][order], m["V"][order]
+
+
+@pytest.mark.parametrize("path", MM, ids=[os.path.basename(p)[3:-4] for p in MM])
+def test_mm_readers_match_scipy(hostio, oracle, path):
+    z = np.load(path[:-4] + ".npz", allow_pickle=False)
+    for reader in (hostio.mm_read, oracle.mm_read):
+        m = reader(path)
+        assert (m["rows"], m["cols"], m["nnz"]) == (int(z["rows"]), int(z["cols"]), len(z["I"]))
+        I, J, V = _sorted(m)
+        assert np.array_equal(I, z["I"]) and np.array_equal(J, z["J"]) and np.array_equal(V, z["V"])
+
+
+def test_mm_roundtrip_and_threads(hostio, oracle, standins, tmp_path):
+    rows, cols, I, J, V = standins.make("scircuit", scale=0.2)   # ~190k lines: exercises the chunked parallel parse
+    p = str(tmp_path / "m.mtx")
+    standins.write_mtx(p, rows, cols, I, J, V)
+    for threads in (1, 5):
+        m = hostio.mm_read(p, threads)
+        assert (m["rows"], m["cols"]) == (rows, cols)
+        assert np.array_equal(m["I"], I) and np.array_equal(m["J"], J) and np.array_equal(m["V"], V)   # file order, exact doubles
+    mo = oracle.mm_read(p)
+    assert np.array_equal(mo["I"], I) and np.array_equal(mo["V"], V)
+
+
+def test_mm_errors(hostio, tmp_path):
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n")
+    with pytest.raises(RuntimeError):
+        hostio.mm_read(str(bad))
+    bad.write_text("%%MatrixMarket matrix coordinate real general\n2 2 1\n3 1 1.0\n")
+    with pytest.raises(RuntimeError):
+        hostio.mm_read(str(bad))
+    with pytest.raises(RuntimeError):
+        hostio.mm_read(str(tmp_path / "missing.mtx"))
+
+
+def test_result_files_format(hostio, tmp_path):
+    hostio.write_result_files(str(tmp_path), [0, 0, 7], [1, 5, 7], [1.5, -0.25, 1e-3])
+    assert (tmp_path / "SPGEMM_RESULT_NNZ.txt").read_text() == "3"                       # no newline (spgemm.cu:1546)
+    assert (tmp_path / "SPGEMM_RESULT_ROWS.txt").read_text() == "0\n0\n7\n"
+    assert (tmp_path / "SPGEMM_RESULT_COLS.txt").read_text() == "1\n5\n7\n"
+    assert (tmp_path / "SPGEMM_RESULT_VALS.txt").read_text().splitlines() == ["%.17f" % v for v in (1.5, -0.25, 1e-3)]
+
+
+def test_csv_record_format(hostio, tmp_path):
+    p = str(tmp_path / "r.csv")
+    kw = dict(matrix="webbase-1M", flop=69524195, c_nnz=51111996, compression_ratio=1.3602, a_conversion_kernel_ms=1.234,
+              b_conversion_kernel_ms=2.0, total_conversion_ms=300.456, step1_ms=1.0, step2_ms=2.5, step3_ms=3.25, spgemm_ms=7.0,
+              kernel_ms=6.75, malloc_ms=0.25, gflops=19.864)
+    hostio.csv_append(p, **kw)
+    hostio.csv_append(p, extra="1,42", **kw)
+    text = open(p).read()
+    want = "\nwebbase-1M,69524195,51111996,1.36,1.23,2.00,300.46,1.00,2.50,3.25,7.00,6.75,0.25,19.86"
+    assert text == want + want + ",1,42"   # "\n" + 14 fields, no header (spgemm.cu:1432-1448)
