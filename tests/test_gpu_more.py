@@ -1,0 +1,139 @@
+"""GPU: boundary behaviour beyond the stage parity -- golden fixtures, CSR input, row slices,
+error paths, the CLI end to end, and full-size properties."""
+import glob
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIXTURES = sorted(glob.glob(os.path.join(GOLD, "spgemm_*.npz")))
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[7:-4] for p in FIXTURES])
+def test_gpu_matches_scipy_fixture(pkg, ctx, path):
+    z = np.load(path, allow_pickle=False)
+    rows, cols, tr = int(z["rows"]), int(z["cols"]), bool(z["transpose"])
+    A = pkg.Tiled.from_coo(ctx, rows, cols, z["I"], z["J"], z["V"], False)
+    B = pkg.Tiled.from_coo(ctx, rows, cols, z["I"], z["J"], z["V"], True) if tr else A
+    plan = pkg.CPlan(ctx, A, B)
+    plan.spgemm()
+    rp, ci, v = plan.export_csr()
+    assert np.array_equal(rp, z["c_rowptr"]) and np.array_equal(ci, z["c_colidx"])      # bit-exact structure
+    np.testing.assert_allclose(v, z["c_vals"], rtol=1e-6, atol=1e-14)                    # north_star: 1e-6 relative fp64
+    np.testing.assert_allclose(v, z["c_vals"], rtol=1e-12, atol=1e-14)                   # what the fma chain actually achieves
+
+
+def test_from_csr_equals_from_coo(pkg, oracle, ctx):
+    from matgen import cases
+    rows, cols, I, J, V, _ = cases()["rand_300"]
+    rp, ci, v = oracle.Csr(rows, cols, I, J, V).arrays()
+    a, b = pkg.Tiled.from_csr(ctx, rows, cols, rp, ci, v), pkg.Tiled.from_coo(ctx, rows, cols, I, J, V)
+    for name in pkg.T_ARRAYS:
+        assert np.array_equal(a.array(name), b.array(name)), name
+
+
+def test_row_slices_concatenate_to_full(pkg, oracle, ctx):
+    from matgen import cases
+    rows, cols, I, J, V, _ = cases()["powerlaw_600"]
+    A = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V)
+    full = pkg.CPlan(ctx, A, A)
+    full.spgemm()
+    frp, fci, fv = full.export_csr()
+    bounds = pkg.split_tile_rows(ctx, A, A, 4)
+    assert bounds[0] == 0 and bounds[-1] == A.tile_rows and np.all(np.diff(bounds) >= 0)
+    parts, oparts = [], []
+    oA = oracle.Tiled(rows, cols, I, J, V)
+    for g in range(4):
+        p = pkg.CPlan(ctx, A, A, int(bounds[g]), int(bounds[g + 1]))
+        p.spgemm()
+        parts.append(p.export_csr())
+        op = oracle.Plan(oA, oA, int(bounds[g]), int(bounds[g + 1]))
+        for name in ("c_tile_rowptr", "c_tile_rowidx", "c_tile_colidx", "pairs_offset", "pairs_a", "pairs_b", "c_mask", "c_vals"):
+            assert np.array_equal(p.array(name), getattr(op, name)), (g, name)
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), fci)
+    assert np.array_equal(np.concatenate([p[2] for p in parts]), fv)
+    offs = np.cumsum([0] + [len(p[1]) for p in parts[:-1]])
+    assert np.array_equal(np.concatenate([[0]] + [p[0][1:] + o for p, o in zip(parts, offs)]), frp)
+
+
+def test_error_paths(pkg, ctx):
+    I = np.array([0, 0, 1], np.int32)
+    with pytest.raises(pkg.PemError) as e:
+        pkg.Tiled.from_coo(ctx, 4, 4, I, I, np.ones(3))
+    assert e.value.status == -2                      # PEM_E_DUPLICATE
+    with pytest.raises(pkg.PemError) as e:
+        pkg.Tiled.from_coo(ctx, 4, 4, np.array([5], np.int32), np.array([0], np.int32), np.ones(1))
+    assert e.value.status == -1                      # PEM_E_INVALID: index out of range
+    A = pkg.Tiled.from_coo(ctx, 4, 6, np.array([1], np.int32), np.array([2], np.int32), np.ones(1))
+    with pytest.raises(pkg.PemError) as e:
+        pkg.CPlan(ctx, A, A)                         # 4x6 times 4x6
+    assert e.value.status == -1
+    B = pkg.Tiled.from_coo(ctx, 4, 6, np.array([1], np.int32), np.array([2], np.int32), np.ones(1), True)
+    p = pkg.CPlan(ctx, A, B)
+    with pytest.raises(pkg.PemError) as e:
+        p.step2()
+    assert e.value.status == -6                      # PEM_E_STATE
+    with pytest.raises(pkg.PemError):
+        p.export_csr()
+    p.spgemm()
+    assert p.info()["nnz_c"] == 1
+
+
+def test_cli_end_to_end(pkg, oracle, standins, tmp_path):
+    hostio = importlib.import_module("pem_spgemm_amd.hostio")
+    rows, cols, I, J, V = standins.make("scircuit", scale=0.01)
+    mtx = str(tmp_path / "mini.mtx")
+    standins.write_mtx(mtx, rows, cols, I, J, V)
+    env = dict(os.environ, PEM_RESULT_DIR=str(tmp_path), PEM_CSV=str(tmp_path / "r.csv"), PEM_REPEAT="2")
+    out = subprocess.run([hostio.CLI_PATH, mtx, "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "<---Program done--->" in out.stdout and "GFlops" in out.stdout
+    a = oracle.Csr(rows, cols, I, J, V)
+    rp, ci, v = oracle.csr_spgemm(a, a).arrays()
+    assert int((tmp_path / "SPGEMM_RESULT_NNZ.txt").read_text()) == len(ci)
+    r_file = np.loadtxt(tmp_path / "SPGEMM_RESULT_ROWS.txt", dtype=np.int64, ndmin=1)
+    c_file = np.loadtxt(tmp_path / "SPGEMM_RESULT_COLS.txt", dtype=np.int64, ndmin=1)
+    v_file = np.loadtxt(tmp_path / "SPGEMM_RESULT_VALS.txt", dtype=np.float64, ndmin=1)
+    assert np.array_equal(r_file, np.repeat(np.arange(rows), np.diff(rp))) and np.array_equal(c_file, ci)
+    np.testing.assert_allclose(v_file, v, rtol=0, atol=5e-18 + 1e-17)     # '%.17f' text round trip
+    rec = (tmp_path / "r.csv").read_text().split("\n")[1].split(",")
+    assert rec[0] == "mini" and int(rec[2]) == len(ci) and len(rec) >= 14
+    # A*A^T through the third argument; rectangular without it is refused (spgemm.cu:782-786)
+    out = subprocess.run([hostio.CLI_PATH, mtx, "0", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "Not saving results" in out.stdout
+
+
+@pytest.mark.parametrize("name,scale", [("scircuit", 1.0), ("mc2depi", 1.0), ("webbase-1M", 1.0)])
+def test_full_size_against_cpu_port(pkg, oracle, standins, ctx, name, scale):
+    """BASELINE sizes: whole C bit-exact against the OpenMP Gustavson port (seconds on the box's
+    host cores) + size-independent properties (checksum identity, sortedness, idempotent re-run)."""
+    rows, cols, I, J, V = standins.make(name, scale)
+    tr = name == "mc2depi"
+    A = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V)
+    B = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V, True) if tr else A
+    plan = pkg.CPlan(ctx, A, B)
+    plan.spgemm()
+    rp, ci, v = plan.export_csr()
+    # sortedness / structure sanity
+    assert rp[0] == 0 and rp[-1] == len(ci) and np.all(np.diff(rp) >= 0)
+    inner = np.ones(len(ci), bool)
+    inner[rp[:-1][np.diff(rp) > 0]] = False
+    assert np.all(np.diff(ci.astype(np.int64))[inner[1:]] > 0), "columns must ascend inside every row"
+    # checksum identity: sum(C) = (1^T A)(B 1) in exact-ish arithmetic (fp64 tolerance on ~1e8 terms)
+    colsum_a = np.bincount(J, weights=V, minlength=cols)
+    rowsum_b = np.bincount(J if tr else I, weights=V, minlength=cols if tr else rows)
+    scale_abs = np.abs(colsum_a) @ np.abs(rowsum_b) + 1.0
+    assert abs(v.sum() - colsum_a @ rowsum_b) <= 1e-9 * scale_abs
+    # flop and sizes against the CPU port, then the whole result bit for bit
+    oa = oracle.Csr(rows, cols, I, J, V)
+    ob = oracle.Csr(rows, cols, I, J, V, True) if tr else oa
+    rp0, ci0, v0 = oracle.csr_spgemm(oa, ob, oracle.max_threads()).arrays()
+    assert np.array_equal(rp, rp0) and np.array_equal(ci, ci0)
+    assert np.array_equal(v, v0)
+    plan.spgemm()
+    rp2, ci2, v2 = plan.export_csr()
+    assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(v2, v)
