@@ -94,7 +94,7 @@ __global__ void conv_fill_kernel(const uint64_t *__restrict__ keys, const uint32
 // ballot returns the four 16-bit transposed rows at once.
 __global__ void __launch_bounds__(256) conv_tile_meta_kernel(const uint8_t *__restrict__ rowcolidx, const int *__restrict__ tile_nnz_ptr,
                                                              long long ntiles, uint16_t *__restrict__ masks, uint8_t *__restrict__ rowptr,
-                                                             uint16_t *__restrict__ masks_t)
+                                                             uint16_t *__restrict__ masks_t, uint32_t *__restrict__ rec)
 {
     long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int r = threadIdx.x & 15;
@@ -126,6 +126,7 @@ __global__ void __launch_bounds__(256) conv_tile_meta_kernel(const uint8_t *__re
         masks[16 * t + r] = (uint16_t)mask;
         rowptr[16 * t + r] = (uint8_t)(inc - cnt);
         masks_t[16 * t + r] = (uint16_t)bt;
+        rec[16 * t + r] = mask | ((unsigned)(inc - cnt) << 16);
     }
 }
 
@@ -360,6 +361,7 @@ static pem_status build_tiled(pem_ctx *ctx, pem_tiled *T, DevBuf &k0, DevBuf &k1
     PEM_TRY(T->masks.reserve(sizeof(uint16_t) * 16 * (nt + 1)));
     PEM_TRY(T->masks_t.reserve(sizeof(uint16_t) * 16 * (nt + 1)));
     PEM_TRY(T->rowptr.reserve(16 * (nt + 1)));
+    PEM_TRY(T->tile_rec.reserve(sizeof(uint32_t) * 16 * (nt + 1)));
     PEM_TRY(T->tile_rowptr.reserve(sizeof(int) * ((size_t)T->tile_rows + 4)));
     PEM_TRY(T->tile_colidx.reserve(sizeof(int) * (nt + 4)));
     PEM_TRY(T->tile_colptr.reserve(sizeof(int) * ((size_t)T->tile_cols + 4)));
@@ -373,7 +375,7 @@ static pem_status build_tiled(pem_ctx *ctx, pem_tiled *T, DevBuf &k0, DevBuf &k1
         PEM_LAUNCH(ctx, conv_fill_kernel, grid_for(nnz, 256), 256, keys, perm, head.as<int>(), nnz, dV, bits_tc, T->vals.as<double>(),
                    T->rowcolidx.as<uint8_t>(), T->tile_keys.as<long long>(), T->tile_nnz_ptr.as<int>());
         PEM_LAUNCH(ctx, conv_tile_meta_kernel, grid_for(nt * 16, 256), 256, T->rowcolidx.as<uint8_t>(), T->tile_nnz_ptr.as<int>(),
-                   (long long)ntiles, T->masks.as<uint16_t>(), T->rowptr.as<uint8_t>(), T->masks_t.as<uint16_t>());
+                   (long long)ntiles, T->masks.as<uint16_t>(), T->rowptr.as<uint8_t>(), T->masks_t.as<uint16_t>(), T->tile_rec.as<uint32_t>());
     }
     PEM_HIP(hipEventRecord(ctx->ev[7], st));
     if (nt) {

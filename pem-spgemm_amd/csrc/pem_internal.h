@@ -163,6 +163,7 @@ struct pem_tiled {
     double conv_ms = 0.0, conv_tile_kernel_ms = 0.0;
     pem::DevBuf tile_keys, tile_nnz_ptr, masks, rowptr, rowcolidx, vals, masks_t;
     pem::DevBuf tile_rowptr, tile_colidx, tile_colptr, tile_rowidx, tile_offsets;
+    pem::DevBuf tile_rec;             // derived: uint32[16T] = masks[16t+r] | rowptr[16t+r] << 16 (one gather serves step 3)
     std::vector<int> h_tile_rowptr;   // host copy (tile_rows+1 ints) for plan creation / splits
 };
 
@@ -179,4 +180,7 @@ struct pem_cplan {
     pem::DevBuf prod_a, prod_b, aprod_off;
     pem::DevBuf sk0, sk1, sv0, sv1;    // sort buffers
     uint32_t *sorted_perm = nullptr;   // points into sv0/sv1
+    // row-local step 1
+    pem::DevBuf row_list, bin_count, xl_base, xl_rowstart, scratch_col, scratch_off;
+    bool pairs_ready = false;          // step 1 already wrote pairs_a / pairs_b
 };

@@ -93,6 +93,217 @@ __global__ void s1_c_rowptr_kernel(const int *__restrict__ c_rowidx, long long n
         for (int row = tr + 1; row <= mt; ++row) c_rowptr[row] = (int)ntc;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// step 1, row-local form (default).  The products of one tile row of A only ever meet
+// products of the same row, so the grouping by C tile is a per-row sort on the tile column:
+// one workgroup expands the row's products into LDS, bitonic-sorts (tile col, product index)
+// keys there, and streams the sorted pair list out once -- no global sort passes.  Rows are
+// binned by their product count (<=128: one wave, <=1024: 256 threads, <=8192: 1024 threads);
+// larger rows take the global expand/radix-sort path above.  C tile columns and per-tile pair
+// offsets go to row-local scratch (a row has at most as many C tiles as products) and are
+// compacted into the reference layout once the per-row tile counts have been scanned.
+// ------------------------------------------------------------------------------------------
+constexpr int S1_CAP0 = 128, S1_CAP1 = 1024, S1_CAP2 = 8192;
+
+__global__ void s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int mt, int a_lo, const int *__restrict__ aprod_off,
+                                   int *__restrict__ row_list, int *__restrict__ bin_count, int *__restrict__ xl_base,
+                                   int *__restrict__ row_tc)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= mt) return;
+    int a0 = a_tile_rowptr[tr_lo + i] - a_lo, a1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
+    int n = aprod_off[a1] - aprod_off[a0];
+    xl_base[i] = -1;
+    row_tc[i] = 0;
+    if (n == 0) return;
+    int bin = n <= S1_CAP0 ? 0 : n <= S1_CAP1 ? 1 : n <= S1_CAP2 ? 2 : 3;
+    int idx = atomicAdd(&bin_count[bin], 1);        // slot order is arbitrary; results do not depend on it
+    row_list[(size_t)bin * mt + idx] = i;
+    if (bin == 3) xl_base[i] = atomicAdd(&bin_count[4], n);
+}
+
+// largest a in [lo, hi) with off[a] <= x
+__device__ __forceinline__ int s1_find_a(const int *__restrict__ off, int lo, int hi, int x)
+{
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (off[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <typename KeyT, int CAP, int QB, int THREADS>
+__global__ void __launch_bounds__(THREADS) s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr,
+                                                             int tr_lo, int a_lo, const int *__restrict__ a_tile_colidx,
+                                                             const int *__restrict__ aprod_off, const int *__restrict__ b_tile_rowptr,
+                                                             const int *__restrict__ b_tile_colidx, int *__restrict__ pairs_a,
+                                                             int *__restrict__ pairs_b, int *__restrict__ scratch_col,
+                                                             int *__restrict__ scratch_off, int *__restrict__ row_tc)
+{
+    __shared__ KeyT keys[CAP];
+    __shared__ int wsum[THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int li = blockIdx.x; li < nrows_bin; li += gridDim.x) {
+        const int i = row_list[li];
+        const int a0 = a_tile_rowptr[tr_lo + i] - a_lo, a1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
+        const int p0 = aprod_off[a0], n = aprod_off[a1] - p0;
+        int npad = 2;
+        while (npad < n) npad <<= 1;
+        // expand: product q of the row -> (A tile, B tile) -> tile column j
+        for (int q = tid; q < npad; q += THREADS) {
+            KeyT key = ~KeyT(0);
+            if (q < n) {
+                int ar = s1_find_a(aprod_off, a0, a1, p0 + q);
+                int k = a_tile_colidx[a_lo + ar];
+                int b = b_tile_rowptr[k] + (p0 + q - aprod_off[ar]);
+                key = (KeyT(b_tile_colidx[b]) << QB) | KeyT(q);
+            }
+            keys[q] = key;
+        }
+        __syncthreads();
+        // bitonic sort in LDS; equal tile columns stay in product (= ascending k) order because q is part of the key
+        for (int kk = 2; kk <= npad; kk <<= 1) {
+            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                for (int t = tid; t < (npad >> 1); t += THREADS) {
+                    int lo = 2 * t - (t & (jj - 1)), hi = lo + jj;
+                    bool up = (lo & kk) == 0;
+                    KeyT x = keys[lo], y = keys[hi];
+                    if ((x > y) == up) {
+                        keys[lo] = y;
+                        keys[hi] = x;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // stream out: sorted pairs, and per distinct tile column (C tile) its column + first pair
+        int base = 0;
+        for (int s0 = 0; s0 < n; s0 += THREADS) {
+            const int s = s0 + tid;
+            const bool valid = s < n;
+            int j = 0, a = 0, b = 0;
+            bool head = false;
+            if (valid) {
+                KeyT key = keys[s];
+                int q = (int)(key & KeyT(CAP - 1));
+                j = (int)(key >> QB);
+                head = s == 0 || (int)(keys[s - 1] >> QB) != j;
+                int ar = s1_find_a(aprod_off, a0, a1, p0 + q);
+                a = a_lo + ar;
+                b = b_tile_rowptr[a_tile_colidx[a]] + (p0 + q - aprod_off[ar]);
+            }
+            unsigned long long bal = __ballot(head);
+            if (lane == 0) wsum[wave] = __popcll(bal);
+            __syncthreads();
+            int woff = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < THREADS / 64; ++w) {
+                int c = wsum[w];
+                if (w < wave) woff += c;
+                tot += c;
+            }
+            if (valid) {
+                pairs_a[p0 + s] = a;
+                pairs_b[p0 + s] = b;
+                if (head) {
+                    int rank = base + woff + __popcll(bal & lt);
+                    scratch_col[p0 + rank] = j;
+                    scratch_off[p0 + rank] = s;
+                }
+            }
+            base += tot;
+            __syncthreads();
+        }
+        if (tid == 0) row_tc[i] = base;
+    }
+}
+
+// rows above S1_CAP2 products: global expand (16 lanes per A tile) + radix sort + emit
+__global__ void __launch_bounds__(256) s1_xl_expand_kernel(const long long *__restrict__ a_tile_keys, const int *__restrict__ a_tile_rowptr,
+                                                           int a_lo, int nA, int tr_lo, const int *__restrict__ aprod_off,
+                                                           const int *__restrict__ xl_base, const int *__restrict__ b_tile_rowptr,
+                                                           const int *__restrict__ b_tile_colidx, int bits_tc, uint64_t *__restrict__ keys,
+                                                           uint32_t *__restrict__ perm, int *__restrict__ prod_a, int *__restrict__ prod_b)
+{
+    int arel = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    int l = threadIdx.x & 15;
+    if (arel >= nA) return;
+    int a = a_lo + arel;
+    long long ak = a_tile_keys[a];
+    int i = (int)(ak >> 32) - tr_lo, k = (int)(ak & 0xFFFFFFFFll);
+    int base = xl_base[i];
+    if (base < 0) return;
+    int a0 = a_tile_rowptr[tr_lo + i] - a_lo;
+    int x0 = base + (aprod_off[arel] - aprod_off[a0]);
+    int b0 = b_tile_rowptr[k], len = b_tile_rowptr[k + 1] - b0;
+    uint64_t hi = (uint64_t)(unsigned)i << bits_tc;
+    for (int q = l; q < len; q += 16) {
+        int x = x0 + q;
+        keys[x] = hi | (uint64_t)(unsigned)b_tile_colidx[b0 + q];
+        perm[x] = (uint32_t)x;
+        prod_a[x] = a;
+        prod_b[x] = b0 + q;
+    }
+}
+
+__global__ void s1_xl_rowstart_kernel(const uint64_t *__restrict__ keys, size_t n, int bits_tc, int *__restrict__ xl_rowstart)
+{
+    size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    int i = (int)(keys[x] >> bits_tc);
+    if (x == 0 || (int)(keys[x - 1] >> bits_tc) != i) xl_rowstart[i] = (int)x;
+}
+
+__global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm, const int *__restrict__ headx, size_t n,
+                                  int bits_tc, const int *__restrict__ xl_rowstart, const int *__restrict__ a_tile_rowptr, int tr_lo, int a_lo,
+                                  const int *__restrict__ aprod_off, const int *__restrict__ prod_a, const int *__restrict__ prod_b,
+                                  int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ scratch_col,
+                                  int *__restrict__ scratch_off, int *__restrict__ row_tc)
+{
+    size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    uint64_t key = keys[x];
+    int i = (int)(key >> bits_tc), j = (int)(key & ((1ull << bits_tc) - 1ull));
+    int rs = xl_rowstart[i];
+    int s = (int)x - rs;
+    int a0 = a_tile_rowptr[tr_lo + i] - a_lo, a1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
+    int p0 = aprod_off[a0], ni = aprod_off[a1] - p0;
+    uint32_t o = perm[x];
+    pairs_a[p0 + s] = prod_a[o];
+    pairs_b[p0 + s] = prod_b[o];
+    int hx = headx[x];
+    if (headx[x + 1] != hx) {
+        int rank = hx - headx[rs];
+        scratch_col[p0 + rank] = j;
+        scratch_off[p0 + rank] = s;
+    }
+    if (s == 0) row_tc[i] = headx[rs + ni] - headx[rs];
+}
+
+// row-local scratch -> reference layout (_C_tileRowIdx/_C_tileColIdx, spgemm.cu:378-379; pair offsets :484)
+__global__ void s1_compact_kernel(const int *__restrict__ c_rowptr, int mt, long long ntc, int tr_lo, const int *__restrict__ a_tile_rowptr,
+                                  int a_lo, const int *__restrict__ aprod_off, const int *__restrict__ scratch_col,
+                                  const int *__restrict__ scratch_off, int npairs, int *__restrict__ c_rowidx, int *__restrict__ c_colidx,
+                                  int *__restrict__ pairs_offset)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntc) return;
+    int lo = 0, hi = mt;   // largest i in [0, mt) with c_rowptr[i] <= t
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (c_rowptr[mid] <= (int)t) lo = mid; else hi = mid;
+    }
+    int i = lo;
+    int r = (int)t - c_rowptr[i];
+    int p0 = aprod_off[a_tile_rowptr[tr_lo + i] - a_lo];
+    c_rowidx[t] = i + tr_lo;
+    c_colidx[t] = scratch_col[p0 + r];
+    pairs_offset[t] = p0 + scratch_off[p0 + r];
+    if (t == ntc - 1) pairs_offset[ntc] = npairs;
+}
+
 // ------------------------------------------------------------------------------------------
 // step 2
 // ------------------------------------------------------------------------------------------
@@ -206,6 +417,153 @@ __global__ void __launch_bounds__(256) s3_accumulate_kernel(
             }
         }
         c_vals[off + n] = acc;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// step 2/3, wide mappings (default).  The 16-lanes-per-tile kernels above issue one vector
+// memory instruction per 4 tiles with most lanes idle (C tiles hold ~3 entries, ~1 pair) and
+// are bound by memory-instruction issue, not bytes.  These forms give every lane a whole
+// unit of work: one C tile per lane for the masks (two 16-byte loads per operand tile, the
+// 16x16 boolean product in registers), one C entry per lane for the numeric step.
+// ------------------------------------------------------------------------------------------
+// a11 + the row-pointer half of a12 (spgemm.cu:499-550, 579-580): one C tile per lane.
+// Two rows share a dword (w[q] = row 2q | row 2q+1 << 16, the natural uint16 layout), so
+// ((Aw >> kk) & 0x00010001) * Brow(kk) ORs B's row kk into both rows at once.
+__global__ void __launch_bounds__(256) s2_cmask_wide_kernel(const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a,
+                                                            const int *__restrict__ pairs_b, long long ntc,
+                                                            const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks,
+                                                            uint32_t *__restrict__ c_mask, int *__restrict__ c_tile_nnz,
+                                                            uint8_t *__restrict__ c_rowptr)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntc) return;
+    const int p0 = pairs_offset[t], p1 = pairs_offset[t + 1];
+    unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = p0; p < p1; ++p) {
+        const int a = pairs_a[p], b = pairs_b[p];
+        const uint4 A0 = *reinterpret_cast<const uint4 *>(a_masks + 16 * (size_t)a);
+        const uint4 A1 = *reinterpret_cast<const uint4 *>(a_masks + 16 * (size_t)a + 8);
+        const uint4 B0 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)b);
+        const uint4 B1 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)b + 8);
+        const unsigned aw[8] = {A0.x, A0.y, A0.z, A0.w, A1.x, A1.y, A1.z, A1.w};
+        const unsigned bw[8] = {B0.x, B0.y, B0.z, B0.w, B1.x, B1.y, B1.z, B1.w};
+        unsigned bk[16];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            bk[2 * q] = bw[q] & 0xFFFFu;
+            bk[2 * q + 1] = bw[q] >> 16;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            unsigned acc = 0;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc |= __umul24((aw[q] >> kk) & 0x00010001u, bk[kk]);
+            cw[q] |= acc;
+        }
+    }
+    // reference packing: word q = (row 2q) << 16 | row 2q+1  (spgemm.cu:533-543)
+    unsigned out[8];
+    unsigned rp[4] = {0, 0, 0, 0};
+    int run = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const unsigned lo = cw[q] & 0xFFFFu, hi = cw[q] >> 16;   // rows 2q, 2q+1
+        out[q] = (lo << 16) | hi;
+        rp[q >> 1] |= (unsigned)run << (16 * (q & 1));
+        run += __popc(lo);
+        rp[q >> 1] |= (unsigned)run << (16 * (q & 1) + 8);
+        run += __popc(hi);
+    }
+    *reinterpret_cast<uint4 *>(c_mask + 8 * t) = make_uint4(out[0], out[1], out[2], out[3]);
+    *reinterpret_cast<uint4 *>(c_mask + 8 * t + 4) = make_uint4(out[4], out[5], out[6], out[7]);
+    *reinterpret_cast<uint4 *>(c_rowptr + 16 * t) = make_uint4(rp[0], rp[1], rp[2], rp[3]);
+    c_tile_nnz[t] = run;
+}
+
+// a12 (spgemm.cu:582-587): packed (r<<4|c) bytes, one C tile per lane
+__global__ void __launch_bounds__(256) s2_crowcol_wide_kernel(const uint32_t *__restrict__ c_mask, const int *__restrict__ c_tile_nnz_ptr,
+                                                              long long ntc, uint8_t *__restrict__ c_rowcolidx)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntc) return;
+    const uint4 M0 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t);
+    const uint4 M1 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t + 4);
+    const unsigned w[8] = {M0.x, M0.y, M0.z, M0.w, M1.x, M1.y, M1.z, M1.w};
+    uint8_t *dst = c_rowcolidx + c_tile_nnz_ptr[t];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        unsigned m = w[q] >> 16;              // row 2q
+        while (m) {
+            int c = __builtin_ctz(m);
+            m &= m - 1;
+            *dst++ = (uint8_t)(((2 * q) << 4) | c);
+        }
+        m = w[q] & 0xFFFFu;                   // row 2q+1
+        while (m) {
+            int c = __builtin_ctz(m);
+            m &= m - 1;
+            *dst++ = (uint8_t)(((2 * q + 1) << 4) | c);
+        }
+    }
+}
+
+// a13 (spgemm.cu:593-661): one C entry per lane.  A wave owns 64 consecutive C tiles; their
+// value offsets and pair ranges sit one per lane in registers, so the entry -> tile lookup is a
+// 6-step shuffle search and costs no memory traffic.  Per (entry, pair): one gather of the A
+// row record (mask | rowptr<<16), one of B's transposed mask; per product one B row record and
+// the two operand values.  Pairs ascend in k-tile, bits ascend, one fma per product: the same
+// chain as the oracle.
+__global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
+    const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b, long long ntc,
+    const int *__restrict__ c_tile_nnz_ptr, const uint8_t *__restrict__ c_rowcolidx, double *__restrict__ c_vals,
+    const int *__restrict__ a_nnz_ptr, const double *__restrict__ a_vals, const uint32_t *__restrict__ a_rec,
+    const int *__restrict__ b_nnz_ptr, const double *__restrict__ b_vals, const uint32_t *__restrict__ b_rec,
+    const uint16_t *__restrict__ b_masks_t)
+{
+    const int lane = threadIdx.x & 63;
+    const long long t0 = (((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 6;   // first tile of this wave
+    if (t0 >= ntc) return;
+    const long long tl = t0 + lane < ntc ? t0 + lane : ntc - 1;
+    const int my_off = (t0 + lane < ntc) ? c_tile_nnz_ptr[tl] : 0x7FFFFFFF;   // value offset of tile t0+lane
+    const int my_p0 = pairs_offset[tl], my_p1 = pairs_offset[tl + 1];
+    const long long tend = t0 + 64 < ntc ? t0 + 64 : ntc;
+    const int e_begin = __shfl(my_off, 0, 64), e_end = c_tile_nnz_ptr[tend];
+    for (int ebase = e_begin; ebase < e_end; ebase += 64) {   // wave-uniform trip count: every lane stays live for the shuffles
+        const int e = ebase + lane;
+        const bool valid = e < e_end;
+        // tile of entry e: largest lane index ti with off[ti] <= e (offsets are non-decreasing)
+        int ti = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            int probe = __shfl(my_off, ti + step, 64);
+            if (probe <= e) ti += step;
+        }
+        const int p0 = __shfl(my_p0, ti, 64), p1 = __shfl(my_p1, ti, 64);
+        if (!valid) continue;
+        const unsigned rc = c_rowcolidx[e];
+        const int r = rc >> 4, c = rc & 15;
+        const unsigned clt = (1u << c) - 1u;
+        double acc = 0.0;
+        for (int p = p0; p < p1; ++p) {
+            const int a = pairs_a[p], b = pairs_b[p];
+            const unsigned aw = a_rec[16 * (size_t)a + r];
+            const unsigned am = aw & 0xFFFFu;
+            unsigned m = am & (unsigned)b_masks_t[16 * (size_t)b + c];
+            if (!m) continue;
+            const double *av = a_vals + a_nnz_ptr[a] + (aw >> 16);
+            const double *bv = b_vals + b_nnz_ptr[b];
+            while (m) {
+                const int kk = __builtin_ctz(m);
+                m &= m - 1;
+                const unsigned bw = b_rec[16 * (size_t)b + kk];
+                const int ao = __popc(am & ((1u << kk) - 1u));
+                const int bo = __popc(bw & clt);
+                acc = __builtin_fma(av[ao], bv[(bw >> 16) + bo], acc);
+            }
+        }
+        c_vals[e] = acc;
     }
 }
 
@@ -327,13 +685,14 @@ static pem_status step_elapsed(pem_ctx *ctx, int e0, double *dst)
     return PEM_OK;
 }
 
-static pem_status step1_impl(pem_ctx *ctx, pem_cplan *p)
+static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
 {
     const pem_tiled *A = p->A, *B = p->B;
     hipStream_t st = ctx->stream;
     const int nA = p->a_hi - p->a_lo, mt = p->tr_hi - p->tr_lo;
     const int bits_tc = bits_for((uint64_t)B->tile_cols), bits_row = bits_for((uint64_t)(mt > 0 ? mt : 1));
     p->state = 0;
+    p->pairs_ready = false;
     p->ntiles_c = p->npairs = p->nnz_c = 0;
     PEM_TRY(zero_flags(ctx));
     PEM_HIP(hipEventRecord(ctx->ev[0], st));
@@ -389,6 +748,126 @@ static pem_status step1_impl(pem_ctx *ctx, pem_cplan *p)
     return PEM_OK;
 }
 
+template <typename KeyT>
+static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int mt)
+{
+    const pem_tiled *A = p->A, *B = p->B;
+    int *rl = p->row_list.as<int>();
+#define PEM_ROWSORT(BIN, CAP, QB, THREADS, MAXGRID)                                                                                  \
+    if (counts[BIN] > 0) {                                                                                                           \
+        int grid = counts[BIN] < (MAXGRID) ? counts[BIN] : (MAXGRID);                                                                \
+        PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<" #CAP ">", (s1_rowsort_kernel<KeyT, CAP, QB, THREADS>), grid, THREADS,             \
+                         rl + (size_t)(BIN) * mt, counts[BIN], A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, A->tile_colidx.as<int>(), \
+                         p->aprod_off.as<int>(), B->tile_rowptr.as<int>(), B->tile_colidx.as<int>(), p->pairs_a.as<int>(),             \
+                         p->pairs_b.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->c_tile_rowptr.as<int>());       \
+    }
+    PEM_ROWSORT(2, 8192, 13, 1024, 1 << 20)
+    PEM_ROWSORT(1, 1024, 10, 256, 1 << 20)
+    PEM_ROWSORT(0, 128, 7, 64, 1 << 20)
+#undef PEM_ROWSORT
+}
+
+static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
+{
+    const pem_tiled *A = p->A, *B = p->B;
+    hipStream_t st = ctx->stream;
+    const int nA = p->a_hi - p->a_lo, mt = p->tr_hi - p->tr_lo;
+    const int bits_tc = bits_for((uint64_t)B->tile_cols), bits_row = bits_for((uint64_t)(mt > 0 ? mt : 1));
+    p->state = 0;
+    p->pairs_ready = false;
+    p->ntiles_c = p->npairs = p->nnz_c = 0;
+    PEM_TRY(zero_flags(ctx));
+    PEM_HIP(hipEventRecord(ctx->ev[0], st));
+    PEM_TRY(p->aprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
+    PEM_TRY(p->c_tile_rowptr.reserve(sizeof(int) * ((size_t)mt + 4)));
+    PEM_TRY(p->row_list.reserve(sizeof(int) * (4 * (size_t)mt + 4)));
+    PEM_TRY(p->bin_count.reserve(sizeof(int) * 8));
+    PEM_TRY(p->xl_base.reserve(sizeof(int) * ((size_t)mt + 4)));
+    PEM_TRY(p->pairs_offset.reserve(sizeof(int) * 4));
+    PEM_HIP(hipMemsetAsync(p->bin_count.p, 0, sizeof(int) * 8, st));
+    PEM_HIP(hipMemsetAsync(p->c_tile_rowptr.p, 0, sizeof(int) * ((size_t)mt + 1), st));
+    PEM_HIP(hipMemsetAsync(p->pairs_offset.p, 0, sizeof(int), st));
+    if (nA > 0)
+        PEM_LAUNCH(ctx, s1_aprod_kernel, grid_for((size_t)nA, 256), 256, A->tile_colidx.as<int>(), p->a_lo, nA, B->tile_rowptr.as<int>(),
+                   p->aprod_off.as<int>());
+    PEM_TRY(exclusive_scan_i32(ctx, p->aprod_off.as<int>(), p->aprod_off.as<int>(), (size_t)nA, ctx->d_scalars));
+    // per-row tile counts are accumulated in c_tile_rowptr and scanned in place afterwards
+    if (mt > 0)
+        PEM_LAUNCH(ctx, s1_rowclass_kernel, grid_for((size_t)mt, 256), 256, A->tile_rowptr.as<int>(), p->tr_lo, mt, p->a_lo,
+                   p->aprod_off.as<int>(), p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(), p->c_tile_rowptr.as<int>());
+    // one read-back: P, the bin populations and the product total of the oversized rows
+    int64_t P = 0;
+    int *hb = reinterpret_cast<int *>(ctx->h_scalars + 32);
+    PEM_HIP(hipMemcpyAsync(hb, p->bin_count.p, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
+    PEM_TRY(read_scalars(ctx, ctx->d_scalars, 1, &P));
+    int counts[4] = {hb[0], hb[1], hb[2], hb[3]};
+    const size_t n_xl = (size_t)hb[4];
+    if (P > 0x7FFFFFFFll) {
+        set_error("step 1: %lld tile pairs exceed the int32 range of the reference's pair arrays", (long long)P);
+        return PEM_E_OVERFLOW;
+    }
+    p->npairs = P;
+    const size_t n = (size_t)P;
+    int64_t TC = 0;
+    if (n > 0) {
+        PEM_TRY(p->pairs_a.reserve(sizeof(int) * (n + 4)));
+        PEM_TRY(p->pairs_b.reserve(sizeof(int) * (n + 4)));
+        PEM_TRY(p->scratch_col.reserve(sizeof(int) * (n + 4)));
+        PEM_TRY(p->scratch_off.reserve(sizeof(int) * (n + 4)));
+        if (bits_tc + 13 <= 32)
+            launch_rowsorts<uint32_t>(ctx, p, counts, mt);
+        else
+            launch_rowsorts<uint64_t>(ctx, p, counts, mt);
+        if (n_xl > 0) {   // oversized rows: global expand + stable radix sort on (row, tile col)
+            PEM_TRY(p->prod_a.reserve(sizeof(int) * n_xl));
+            PEM_TRY(p->prod_b.reserve(sizeof(int) * n_xl));
+            PEM_TRY(p->sk0.reserve(sizeof(uint64_t) * n_xl));
+            PEM_TRY(p->sk1.reserve(sizeof(uint64_t) * n_xl));
+            PEM_TRY(p->sv0.reserve(sizeof(uint32_t) * n_xl));
+            PEM_TRY(p->sv1.reserve(sizeof(uint32_t) * n_xl));
+            PEM_TRY(p->xl_rowstart.reserve(sizeof(int) * ((size_t)mt + 4)));
+            PEM_LAUNCH(ctx, s1_xl_expand_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_keys.as<long long>(), A->tile_rowptr.as<int>(),
+                       p->a_lo, nA, p->tr_lo, p->aprod_off.as<int>(), p->xl_base.as<int>(), B->tile_rowptr.as<int>(), B->tile_colidx.as<int>(),
+                       bits_tc, p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(), p->prod_a.as<int>(), p->prod_b.as<int>());
+            uint64_t *keys = nullptr;
+            uint32_t *perm = nullptr;
+            PEM_TRY(radix_sort_u64_u32(ctx, p->sk0.as<uint64_t>(), p->sk1.as<uint64_t>(), p->sv0.as<uint32_t>(), p->sv1.as<uint32_t>(), n_xl,
+                                       bits_tc + bits_row, &keys, &perm));
+            DevBuf &head = ctx->tmp[2];
+            PEM_TRY(head.reserve(sizeof(int) * (n_xl + 4)));
+            PEM_LAUNCH(ctx, s1_heads_kernel, grid_for(n_xl, 256), 256, keys, n_xl, head.as<int>());
+            PEM_TRY(exclusive_scan_i32(ctx, head.as<int>(), head.as<int>(), n_xl, nullptr));
+            PEM_LAUNCH(ctx, s1_xl_rowstart_kernel, grid_for(n_xl, 256), 256, keys, n_xl, bits_tc, p->xl_rowstart.as<int>());
+            PEM_LAUNCH(ctx, s1_xl_emit_kernel, grid_for(n_xl, 256), 256, keys, perm, head.as<int>(), n_xl, bits_tc, p->xl_rowstart.as<int>(),
+                       A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->aprod_off.as<int>(), p->prod_a.as<int>(), p->prod_b.as<int>(),
+                       p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(),
+                       p->c_tile_rowptr.as<int>());
+        }
+        // _C_rowPtr = exclusive scan of the per-row tile counts (spgemm.cu:1168); total = T_C
+        PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_rowptr.as<int>(), p->c_tile_rowptr.as<int>(), (size_t)mt, ctx->d_scalars + 1));
+        PEM_TRY(read_scalars(ctx, ctx->d_scalars + 1, 1, &TC));
+        const size_t ntc = (size_t)TC;
+        PEM_TRY(p->c_tile_rowidx.reserve(sizeof(int) * (ntc + 4)));
+        PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
+        PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
+        PEM_LAUNCH(ctx, s1_compact_kernel, grid_for(ntc, 256), 256, p->c_tile_rowptr.as<int>(), mt, (long long)TC, p->tr_lo,
+                   A->tile_rowptr.as<int>(), p->a_lo, p->aprod_off.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), (int)P,
+                   p->c_tile_rowidx.as<int>(), p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>());
+        p->pairs_ready = true;
+    }
+    p->ntiles_c = TC;
+    PEM_HIP(hipEventRecord(ctx->ev[1], st));
+    p->state = 1;
+    return PEM_OK;
+}
+
+static pem_status step1_impl(pem_ctx *ctx, pem_cplan *p)
+{
+    const char *mode = getenv("PEM_STEP1");
+    if (mode && !strcmp(mode, "esc")) return step1_esc_impl(ctx, p);
+    return step1_rows_impl(ctx, p);
+}
+
 static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
 {
     if (p->state < 1) {
@@ -404,12 +883,20 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
     PEM_TRY(p->c_mask.reserve(sizeof(uint32_t) * 8 * (ntc + 1)));
     PEM_TRY(p->c_tile_nnz_ptr.reserve(sizeof(int) * (ntc + 4)));
     PEM_TRY(p->c_rowptr.reserve(16 * (ntc + 1)));
-    if (n > 0)
+    if (n > 0 && !p->pairs_ready)
         PEM_LAUNCH(ctx, s2_pairs_kernel, grid_for(n, 256), 256, p->sorted_perm, p->prod_a.as<int>(), p->prod_b.as<int>(), n, p->pairs_a.as<int>(),
                    p->pairs_b.as<int>());
-    if (ntc > 0)
-        PEM_LAUNCH(ctx, s2_cmask_kernel, grid_for(ntc * 16, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
-                   (long long)ntc, A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>());
+    const char *wide_env = getenv("PEM_WIDE");
+    const bool wide = !(wide_env && !strcmp(wide_env, "0"));
+    if (ntc > 0) {
+        if (wide)
+            PEM_LAUNCH(ctx, s2_cmask_wide_kernel, grid_for(ntc, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
+                       (long long)ntc, A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>(),
+                       p->c_rowptr.as<uint8_t>());
+        else
+            PEM_LAUNCH(ctx, s2_cmask_kernel, grid_for(ntc * 16, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
+                       (long long)ntc, A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>());
+    }
     PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_nnz_ptr.as<int>(), p->c_tile_nnz_ptr.as<int>(), ntc, ctx->d_scalars + 2));
     int64_t nnzc = 0;
     PEM_TRY(read_scalars(ctx, ctx->d_scalars + 2, 1, &nnzc));
@@ -420,9 +907,14 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
     p->nnz_c = nnzc;
     PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
     PEM_TRY(p->c_vals.reserve(sizeof(double) * ((size_t)nnzc + 1)));
-    if (ntc > 0)
-        PEM_LAUNCH(ctx, s2_crowcol_kernel, grid_for(ntc * 16, 256), 256, p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
-                   p->c_rowptr.as<uint8_t>(), p->c_rowcolidx.as<uint8_t>());
+    if (ntc > 0) {
+        if (wide)
+            PEM_LAUNCH(ctx, s2_crowcol_wide_kernel, grid_for(ntc, 256), 256, p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
+                       p->c_rowcolidx.as<uint8_t>());
+        else
+            PEM_LAUNCH(ctx, s2_crowcol_kernel, grid_for(ntc * 16, 256), 256, p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
+                       p->c_rowptr.as<uint8_t>(), p->c_rowcolidx.as<uint8_t>());
+    }
     PEM_HIP(hipEventRecord(ctx->ev[3], st));
     p->state = 2;
     return PEM_OK;
@@ -438,7 +930,14 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
     hipStream_t st = ctx->stream;
     const size_t ntc = (size_t)p->ntiles_c;
     PEM_HIP(hipEventRecord(ctx->ev[4], st));
-    if (ntc > 0)
+    const char *wide_env = getenv("PEM_WIDE");
+    const bool wide = !(wide_env && !strcmp(wide_env, "0"));
+    if (ntc > 0 && wide)
+        PEM_LAUNCH(ctx, s3_accumulate_wide_kernel, grid_for(ntc, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
+                   (long long)ntc, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<double>(), A->tile_nnz_ptr.as<int>(),
+                   A->vals.as<double>(), A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals.as<double>(), B->tile_rec.as<uint32_t>(),
+                   B->masks_t.as<uint16_t>());
+    else if (ntc > 0)
         PEM_LAUNCH(ctx, s3_accumulate_kernel, grid_for(ntc * 16, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
                    (long long)ntc, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<double>(), A->tile_nnz_ptr.as<int>(),
                    A->vals.as<double>(), A->masks.as<uint16_t>(), A->rowptr.as<uint8_t>(), B->tile_nnz_ptr.as<int>(), B->vals.as<double>(),

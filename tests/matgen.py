@@ -62,4 +62,17 @@ def cases():
     out["diag_100"] = (100, 100, np.arange(100, dtype=np.int32), np.arange(100, dtype=np.int32), _vals(rng, 100), False)
     # wide: more than 16384 tile columns (the reference's step-1 dispatch boundary, spgemm.cu:1142)
     out["wide_tilecols"] = random_coo(rng, 16385 * 16, 64, 900) + (True,)
+    # tile rows with many products: 40 tiles x 40 tiles (1600 products/row: 1024-thread LDS bin) and
+    # 100 x 100 (10000 products/row: beyond the LDS bins -> global radix-sort path), plus one hub row
+    for nm, ntc in (("blockrows_1600", 40), ("blockrows_10000", 100)):
+        n = 16 * ntc
+        I = np.repeat(np.arange(n), ntc)
+        J = (np.tile(np.arange(ntc), n) * 16 + (I * 7 + np.tile(np.arange(ntc), n) * 3) % 16)
+        p = rng.permutation(len(I))
+        out[nm] = (n, n, I[p].astype(np.int32), J[p].astype(np.int32), _vals(rng, len(I)), False)
+    n = 4000
+    I = np.concatenate([np.full(n, 5), np.arange(n), rng.integers(0, n, 6000)])
+    J = np.concatenate([np.arange(n), np.arange(n), rng.integers(0, n, 6000)])
+    key = rng.permutation(np.unique(I.astype(np.int64) * n + J))
+    out["hub_row_4000"] = (n, n, (key // n).astype(np.int32), (key % n).astype(np.int32), _vals(rng, len(key)), False)
     return out

@@ -72,3 +72,27 @@ def test_one_shot_spgemm_and_rerun(pkg, oracle, ctx):
         assert np.array_equal(a, b)
     t = ctx.timings()
     assert t["spgemm_wall_ms"] > 0 and t["step3_ms"] >= 0
+
+
+@pytest.mark.parametrize("name", ["powerlaw_600", "blockrows_10000", "dense_48", "empty_matrix"])
+def test_global_sort_step1_matches_row_local_step1(pkg, oracle, ctx, name, monkeypatch):
+    """PEM_STEP1=esc selects the global expand/radix-sort step 1 (also the path of oversized rows)."""
+    monkeypatch.setenv("PEM_STEP1", "esc")
+    gA, gB, oA, oB = _tiled_pair(pkg, oracle, ctx, CASES[name])
+    plan = pkg.CPlan(ctx, gA, gB)
+    plan.spgemm()
+    op = oracle.Plan(oA, oB)
+    for arr in C_NAMES:
+        assert np.array_equal(plan.array(arr), getattr(op, arr)), f"{name}: plan array {arr} differs (esc)"
+
+
+@pytest.mark.parametrize("name", ["powerlaw_600", "dense_48", "rect_70x40_AAt", "hub_row_4000", "empty_matrix"])
+def test_narrow_step23_kernels_match(pkg, oracle, ctx, name, monkeypatch):
+    """PEM_WIDE=0 selects the 16-lanes-per-tile step 2/3 kernels (kept as the A/B baseline)."""
+    monkeypatch.setenv("PEM_WIDE", "0")
+    gA, gB, oA, oB = _tiled_pair(pkg, oracle, ctx, CASES[name])
+    plan = pkg.CPlan(ctx, gA, gB)
+    plan.spgemm()
+    op = oracle.Plan(oA, oB)
+    for arr in C_NAMES:
+        assert np.array_equal(plan.array(arr), getattr(op, arr)), f"{name}: plan array {arr} differs (narrow)"
