@@ -106,21 +106,33 @@ __global__ void s1_c_rowptr_kernel(const int *__restrict__ c_rowidx, long long n
 // ------------------------------------------------------------------------------------------
 constexpr int S1_CAP0 = 128, S1_CAP1 = 1024, S1_CAP2 = 8192;
 
-__global__ void s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int mt, int a_lo, const int *__restrict__ aprod_off,
-                                   int *__restrict__ row_list, int *__restrict__ bin_count, int *__restrict__ xl_base,
-                                   int *__restrict__ row_tc)
+__global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int mt, int a_lo,
+                                                          const int *__restrict__ aprod_off, int *__restrict__ row_list,
+                                                          int *__restrict__ bin_count, int *__restrict__ xl_base, int *__restrict__ row_tc)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= mt) return;
-    int a0 = a_tile_rowptr[tr_lo + i] - a_lo, a1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
-    int n = aprod_off[a1] - aprod_off[a0];
-    xl_base[i] = -1;
-    row_tc[i] = 0;
-    if (n == 0) return;
-    int bin = n <= S1_CAP0 ? 0 : n <= S1_CAP1 ? 1 : n <= S1_CAP2 ? 2 : 3;
-    int idx = atomicAdd(&bin_count[bin], 1);        // slot order is arbitrary; results do not depend on it
-    row_list[(size_t)bin * mt + idx] = i;
-    if (bin == 3) xl_base[i] = atomicAdd(&bin_count[4], n);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int n = 0;
+    if (i < mt) {
+        int a0 = a_tile_rowptr[tr_lo + i] - a_lo, a1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
+        n = aprod_off[a1] - aprod_off[a0];
+        xl_base[i] = -1;
+        row_tc[i] = 0;
+    }
+    const int bin = n == 0 ? -1 : n <= S1_CAP0 ? 0 : n <= S1_CAP1 ? 1 : n <= S1_CAP2 ? 2 : 3;
+    // one atomic per wave and bin: ballot + prefix popcount hand out the slots (order is irrelevant)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        unsigned long long m = __ballot(bin == b);
+        if (m == 0) continue;
+        int leader = __builtin_ctzll(m);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&bin_count[b], __popcll(m));
+        base = __shfl(base, leader, 64);
+        if (bin == b) row_list[(size_t)b * mt + base + __popcll(m & lt)] = i;
+    }
+    if (bin == 3) xl_base[i] = atomicAdd(&bin_count[4], n);   // oversized rows are few
 }
 
 // largest a in [lo, hi) with off[a] <= x
@@ -133,7 +145,110 @@ __device__ __forceinline__ int s1_find_a(const int *__restrict__ off, int lo, in
     return lo;
 }
 
-template <typename KeyT, int CAP, int QB, int THREADS>
+// Bitonic sort of THREADS*EPT keys held EPT per thread (element e = m*THREADS + tid).  Strides
+// below 64 exchange by wave shuffle, strides >= THREADS are register-local, only the strides in
+// [64, THREADS) go through LDS -- 5 of the 45 stages at 512 keys.  Ends with the keys in `lds`.
+template <typename KeyT> __device__ __forceinline__ KeyT s1_shfl_xor(KeyT v, int mask);
+template <> __device__ __forceinline__ uint32_t s1_shfl_xor<uint32_t>(uint32_t v, int mask) { return (uint32_t)__shfl_xor((int)v, mask, 64); }
+template <> __device__ __forceinline__ uint64_t s1_shfl_xor<uint64_t>(uint64_t v, int mask)
+{
+    return (uint64_t)__shfl_xor((unsigned long long)v, mask, 64);
+}
+
+template <typename KeyT, int THREADS, int EPT, int LOGT>
+__device__ __forceinline__ void s1_bitonic_regs(KeyT (&v)[EPT], KeyT *lds, const int tid)
+{
+    constexpr int LOGE = EPT == 1 ? 0 : EPT == 2 ? 1 : EPT == 4 ? 2 : 3;
+    constexpr int LOGNP = LOGT + LOGE;
+#pragma unroll
+    for (int lk = 1; lk <= LOGNP; ++lk) {
+        const int kk = 1 << lk;
+#pragma unroll
+        for (int lj = lk - 1; lj >= 0; --lj) {
+            const int jj = 1 << lj;
+            if (lj >= LOGT) {            // partner in another register of this thread
+                const int dm = jj / THREADS;
+#pragma unroll
+                for (int m = 0; m < EPT; ++m) {
+                    if ((m & dm) == 0 && (m | dm) < EPT) {
+                        const int m2 = m | dm;
+                        const bool up = (((m * THREADS) | tid) & kk) == 0;
+                        const KeyT x = v[m], y = v[m2];
+                        const bool sw = (x > y) == up;
+                        v[m] = sw ? y : x;
+                        v[m2] = sw ? x : y;
+                    }
+                }
+            } else if (lj < 6) {         // partner in another lane of this wave
+#pragma unroll
+                for (int m = 0; m < EPT; ++m) {
+                    const KeyT pv = s1_shfl_xor<KeyT>(v[m], jj);
+                    const bool up = (((m * THREADS) | tid) & kk) == 0;
+                    const bool lower = (tid & jj) == 0;
+                    const KeyT mn = v[m] < pv ? v[m] : pv, mx = v[m] < pv ? pv : v[m];
+                    v[m] = (lower == up) ? mn : mx;
+                }
+            } else {                     // partner in another wave: through LDS
+#pragma unroll
+                for (int m = 0; m < EPT; ++m) lds[m * THREADS + tid] = v[m];
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < EPT; ++m) {
+                    const KeyT pv = lds[(m * THREADS + tid) ^ jj];
+                    const bool up = (((m * THREADS) | tid) & kk) == 0;
+                    const bool lower = (tid & jj) == 0;
+                    const KeyT mn = v[m] < pv ? v[m] : pv, mx = v[m] < pv ? pv : v[m];
+                    v[m] = (lower == up) ? mn : mx;
+                }
+                __syncthreads();
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < EPT; ++m) lds[m * THREADS + tid] = v[m];
+    __syncthreads();
+}
+
+template <typename KeyT, int CAP, int QB, int THREADS, int RCAP>
+struct S1Row {
+    KeyT *keys;
+    const int *roff, *rbs;
+    bool staged;
+    int R, a0, a1, p0, n, a_lo;
+    const int *a_tile_colidx, *aprod_off, *b_tile_rowptr, *b_tile_colidx;
+    __device__ __forceinline__ int tile_b(int q, int *a_out) const
+    {
+        int ar, b;
+        if (staged) {
+            ar = s1_find_a(roff, 0, R, q);
+            b = rbs[ar] + (q - roff[ar]);
+            ar += a0;
+        } else {
+            ar = s1_find_a(aprod_off, a0, a1, p0 + q);
+            b = b_tile_rowptr[a_tile_colidx[a_lo + ar]] + (p0 + q - aprod_off[ar]);
+        }
+        *a_out = a_lo + ar;
+        return b;
+    }
+    template <int EPT, int LOGT> __device__ __forceinline__ void expand_and_sort(const int tid) const
+    {
+        KeyT v[EPT];
+#pragma unroll
+        for (int m = 0; m < EPT; ++m) {
+            const int q = m * THREADS + tid;
+            KeyT key = ~KeyT(0);
+            if (q < n) {
+                int a;
+                const int b = tile_b(q, &a);
+                key = (KeyT(b_tile_colidx[b]) << QB) | KeyT(q);
+            }
+            v[m] = key;
+        }
+        s1_bitonic_regs<KeyT, THREADS, EPT, LOGT>(v, keys, tid);
+    }
+};
+
+template <typename KeyT, int CAP, int QB, int THREADS, int RCAP>
 __global__ void __launch_bounds__(THREADS) s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr,
                                                              int tr_lo, int a_lo, const int *__restrict__ a_tile_colidx,
                                                              const int *__restrict__ aprod_off, const int *__restrict__ b_tile_rowptr,
@@ -141,43 +256,48 @@ __global__ void __launch_bounds__(THREADS) s1_rowsort_kernel(const int *__restri
                                                              int *__restrict__ pairs_b, int *__restrict__ scratch_col,
                                                              int *__restrict__ scratch_off, int *__restrict__ row_tc)
 {
+    constexpr int LOGT = THREADS == 64 ? 6 : THREADS == 256 ? 8 : 10;
+    constexpr int EMAX = CAP / THREADS;
+    static_assert(EMAX == 2 || EMAX == 4 || EMAX == 8, "CAP must be 2, 4 or 8 keys per thread");
     __shared__ KeyT keys[CAP];
+    __shared__ int roff[RCAP + 1];     // product offset of every A tile of the row, relative to the row
+    __shared__ int rbs[RCAP];          // first B tile id of that A tile's B tile row
     __shared__ int wsum[THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int li = blockIdx.x; li < nrows_bin; li += gridDim.x) {
         const int i = row_list[li];
-        const int a0 = a_tile_rowptr[tr_lo + i] - a_lo, a1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
-        const int p0 = aprod_off[a0], n = aprod_off[a1] - p0;
-        int npad = 2;
-        while (npad < n) npad <<= 1;
-        // expand: product q of the row -> (A tile, B tile) -> tile column j
-        for (int q = tid; q < npad; q += THREADS) {
-            KeyT key = ~KeyT(0);
-            if (q < n) {
-                int ar = s1_find_a(aprod_off, a0, a1, p0 + q);
-                int k = a_tile_colidx[a_lo + ar];
-                int b = b_tile_rowptr[k] + (p0 + q - aprod_off[ar]);
-                key = (KeyT(b_tile_colidx[b]) << QB) | KeyT(q);
+        S1Row<KeyT, CAP, QB, THREADS, RCAP> row;
+        row.keys = keys;
+        row.roff = roff;
+        row.rbs = rbs;
+        row.a_lo = a_lo;
+        row.a_tile_colidx = a_tile_colidx;
+        row.aprod_off = aprod_off;
+        row.b_tile_rowptr = b_tile_rowptr;
+        row.b_tile_colidx = b_tile_colidx;
+        row.a0 = a_tile_rowptr[tr_lo + i] - a_lo;
+        row.a1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
+        row.R = row.a1 - row.a0;
+        row.p0 = aprod_off[row.a0];
+        row.n = aprod_off[row.a1] - row.p0;
+        row.staged = row.R <= RCAP;   // the row's A-tile table fits in LDS (else: search it in global memory)
+        const int n = row.n, p0 = row.p0;
+        if (row.staged) {
+            for (int x = tid; x <= row.R; x += THREADS) {
+                roff[x] = aprod_off[row.a0 + x] - p0;
+                if (x < row.R) rbs[x] = b_tile_rowptr[a_tile_colidx[a_lo + row.a0 + x]];
             }
-            keys[q] = key;
         }
         __syncthreads();
-        // bitonic sort in LDS; equal tile columns stay in product (= ascending k) order because q is part of the key
-        for (int kk = 2; kk <= npad; kk <<= 1) {
-            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
-                for (int t = tid; t < (npad >> 1); t += THREADS) {
-                    int lo = 2 * t - (t & (jj - 1)), hi = lo + jj;
-                    bool up = (lo & kk) == 0;
-                    KeyT x = keys[lo], y = keys[hi];
-                    if ((x > y) == up) {
-                        keys[lo] = y;
-                        keys[hi] = x;
-                    }
-                }
-                __syncthreads();
-            }
-        }
+        // expand the row's products into (tile col, product index) keys and sort them; equal tile
+        // columns stay in product (= ascending k) order because the index is part of the key
+        if (n <= THREADS * (EMAX / 4) && EMAX >= 4)
+            row.template expand_and_sort<(EMAX >= 4 ? EMAX / 4 : 1), LOGT>(tid);
+        else if (n <= THREADS * (EMAX / 2))
+            row.template expand_and_sort<EMAX / 2, LOGT>(tid);
+        else
+            row.template expand_and_sort<EMAX, LOGT>(tid);
         // stream out: sorted pairs, and per distinct tile column (C tile) its column + first pair
         int base = 0;
         for (int s0 = 0; s0 < n; s0 += THREADS) {
@@ -190,9 +310,7 @@ __global__ void __launch_bounds__(THREADS) s1_rowsort_kernel(const int *__restri
                 int q = (int)(key & KeyT(CAP - 1));
                 j = (int)(key >> QB);
                 head = s == 0 || (int)(keys[s - 1] >> QB) != j;
-                int ar = s1_find_a(aprod_off, a0, a1, p0 + q);
-                a = a_lo + ar;
-                b = b_tile_rowptr[a_tile_colidx[a]] + (p0 + q - aprod_off[ar]);
+                b = row.tile_b(q, &a);
             }
             unsigned long long bal = __ballot(head);
             if (lane == 0) wsum[wave] = __popcll(bal);
@@ -283,21 +401,34 @@ __global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint3
 }
 
 // row-local scratch -> reference layout (_C_tileRowIdx/_C_tileColIdx, spgemm.cu:378-379; pair offsets :484)
-__global__ void s1_compact_kernel(const int *__restrict__ c_rowptr, int mt, long long ntc, int tr_lo, const int *__restrict__ a_tile_rowptr,
-                                  int a_lo, const int *__restrict__ aprod_off, const int *__restrict__ scratch_col,
-                                  const int *__restrict__ scratch_off, int npairs, int *__restrict__ c_rowidx, int *__restrict__ c_colidx,
-                                  int *__restrict__ pairs_offset)
+__global__ void __launch_bounds__(256) s1_compact_kernel(const int *__restrict__ c_rowptr, int mt, long long ntc, int tr_lo,
+                                                         const int *__restrict__ a_tile_rowptr, int a_lo, const int *__restrict__ aprod_off,
+                                                         const int *__restrict__ scratch_col, const int *__restrict__ scratch_off, int npairs,
+                                                         int *__restrict__ c_rowidx, int *__restrict__ c_colidx, int *__restrict__ pairs_offset)
 {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int win[2];
+    const long long tb = (long long)blockIdx.x * blockDim.x;
+    // the block's 256 consecutive tiles span few tile rows: two full searches bound the window
+    if (threadIdx.x < 2) {
+        long long tt = threadIdx.x == 0 ? tb : (tb + 255 < ntc ? tb + 255 : ntc - 1);
+        int lo = 0, hi = mt;   // largest i in [0, mt) with c_rowptr[i] <= tt
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (c_rowptr[mid] <= (int)tt) lo = mid; else hi = mid;
+        }
+        win[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    const long long t = tb + threadIdx.x;
     if (t >= ntc) return;
-    int lo = 0, hi = mt;   // largest i in [0, mt) with c_rowptr[i] <= t
+    int lo = win[0], hi = win[1] + 1;
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
         if (c_rowptr[mid] <= (int)t) lo = mid; else hi = mid;
     }
-    int i = lo;
-    int r = (int)t - c_rowptr[i];
-    int p0 = aprod_off[a_tile_rowptr[tr_lo + i] - a_lo];
+    const int i = lo;
+    const int r = (int)t - c_rowptr[i];
+    const int p0 = aprod_off[a_tile_rowptr[tr_lo + i] - a_lo];
     c_rowidx[t] = i + tr_lo;
     c_colidx[t] = scratch_col[p0 + r];
     pairs_offset[t] = p0 + scratch_off[p0 + r];
@@ -753,17 +884,17 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
 {
     const pem_tiled *A = p->A, *B = p->B;
     int *rl = p->row_list.as<int>();
-#define PEM_ROWSORT(BIN, CAP, QB, THREADS, MAXGRID)                                                                                  \
+#define PEM_ROWSORT(BIN, CAP, QB, THREADS, RCAP, MAXGRID)                                                                                 \
     if (counts[BIN] > 0) {                                                                                                           \
         int grid = counts[BIN] < (MAXGRID) ? counts[BIN] : (MAXGRID);                                                                \
-        PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<" #CAP ">", (s1_rowsort_kernel<KeyT, CAP, QB, THREADS>), grid, THREADS,             \
+        PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<" #CAP ">", (s1_rowsort_kernel<KeyT, CAP, QB, THREADS, RCAP>), grid, THREADS,             \
                          rl + (size_t)(BIN) * mt, counts[BIN], A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, A->tile_colidx.as<int>(), \
                          p->aprod_off.as<int>(), B->tile_rowptr.as<int>(), B->tile_colidx.as<int>(), p->pairs_a.as<int>(),             \
                          p->pairs_b.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->c_tile_rowptr.as<int>());       \
     }
-    PEM_ROWSORT(2, 8192, 13, 1024, 1 << 20)
-    PEM_ROWSORT(1, 1024, 10, 256, 1 << 20)
-    PEM_ROWSORT(0, 128, 7, 64, 1 << 20)
+    PEM_ROWSORT(2, 8192, 13, 1024, 2048, 1 << 20)
+    PEM_ROWSORT(1, 1024, 10, 256, 1024, 1 << 20)
+    PEM_ROWSORT(0, 128, 7, 64, 128, 1 << 20)
 #undef PEM_ROWSORT
 }
 

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc CSVs (one directory per counter pass) into a per-kernel table.
+Counter values are averaged per dispatch; FETCH_SIZE is doubled per the gfx950 correction in
+/opt/skills/guides/MI355X_MICROARCH.md (HBM section: FETCH_SIZE reads 1/2 of wide coalesced reads)
+and both sizes are reported in bytes (the counters are in KiB)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+per = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> [values]
+dur = defaultdict(list)
+for path in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recursive=True):
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            name = row.get("Kernel_Name", "")
+            short = name.split("(")[0].replace("pem::", "").replace("void ", "")
+            per[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for path in glob.glob(os.path.join(out, "sq", "**", "*kernel_trace.csv"), recursive=True):
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            short = row["Kernel_Name"].split("(")[0].replace("pem::", "").replace("void ", "")
+            dur[short].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+cols = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_LDS",
+        "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]
+print("kernel".ljust(34), "calls".rjust(5), "avg_us".rjust(9), " ".join(c.replace("SQ_", "").rjust(14) for c in cols))
+rows = []
+for k, cs in per.items():
+    n = max(len(v) for v in cs.values())
+    avg = {c: (sum(cs[c]) / len(cs[c]) if cs.get(c) else float("nan")) for c in cols}
+    avg["FETCH_SIZE"] = avg["FETCH_SIZE"] * 1024 * 2     # KiB -> bytes, gfx950 x2 correction
+    avg["WRITE_SIZE"] = avg["WRITE_SIZE"] * 1024
+    d = sum(dur[k]) / len(dur[k]) if dur.get(k) else float("nan")
+    rows.append((d * len(dur.get(k, [])), k, n, d, avg))
+for _, k, n, d, avg in sorted(rows, reverse=True):
+    print(k[:34].ljust(34), str(len(dur.get(k, []))).rjust(5), f"{d:9.1f}", " ".join(f"{avg[c]:14.4g}" for c in cols))
