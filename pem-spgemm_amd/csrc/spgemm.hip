@@ -104,7 +104,7 @@ __global__ void s1_c_rowptr_kernel(const int *__restrict__ c_rowidx, long long n
 // offsets go to row-local scratch (a row has at most as many C tiles as products) and are
 // compacted into the reference layout once the per-row tile counts have been scanned.
 // ------------------------------------------------------------------------------------------
-constexpr int S1_CAP0 = 128, S1_CAP1 = 1024, S1_CAP2 = 8192;
+constexpr int S1_CAP0 = 512, S1_CAP1 = 2048, S1_CAP2 = 8192;
 
 __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int mt, int a_lo,
                                                           const int *__restrict__ aprod_off, int *__restrict__ row_list,
@@ -158,7 +158,7 @@ template <> __device__ __forceinline__ uint64_t s1_shfl_xor<uint64_t>(uint64_t v
 template <typename KeyT, int THREADS, int EPT, int LOGT>
 __device__ __forceinline__ void s1_bitonic_regs(KeyT (&v)[EPT], KeyT *lds, const int tid)
 {
-    constexpr int LOGE = EPT == 1 ? 0 : EPT == 2 ? 1 : EPT == 4 ? 2 : 3;
+    constexpr int LOGE = EPT == 1 ? 0 : EPT == 2 ? 1 : EPT == 4 ? 2 : EPT == 8 ? 3 : 4;
     constexpr int LOGNP = LOGT + LOGE;
 #pragma unroll
     for (int lk = 1; lk <= LOGNP; ++lk) {
@@ -249,7 +249,7 @@ struct S1Row {
 };
 
 template <typename KeyT, int CAP, int QB, int THREADS, int RCAP>
-__global__ void __launch_bounds__(THREADS) s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr,
+__global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr,
                                                              int tr_lo, int a_lo, const int *__restrict__ a_tile_colidx,
                                                              const int *__restrict__ aprod_off, const int *__restrict__ b_tile_rowptr,
                                                              const int *__restrict__ b_tile_colidx, int *__restrict__ pairs_a,
@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(THREADS) s1_rowsort_kernel(const int *__restri
 {
     constexpr int LOGT = THREADS == 64 ? 6 : THREADS == 256 ? 8 : 10;
     constexpr int EMAX = CAP / THREADS;
-    static_assert(EMAX == 2 || EMAX == 4 || EMAX == 8, "CAP must be 2, 4 or 8 keys per thread");
+    static_assert(EMAX == 8, "each bin sorts up to 8 keys per thread");
     __shared__ KeyT keys[CAP];
     __shared__ int roff[RCAP + 1];     // product offset of every A tile of the row, relative to the row
     __shared__ int rbs[RCAP];          // first B tile id of that A tile's B tile row
@@ -292,12 +292,14 @@ __global__ void __launch_bounds__(THREADS) s1_rowsort_kernel(const int *__restri
         __syncthreads();
         // expand the row's products into (tile col, product index) keys and sort them; equal tile
         // columns stay in product (= ascending k) order because the index is part of the key
-        if (n <= THREADS * (EMAX / 4) && EMAX >= 4)
-            row.template expand_and_sort<(EMAX >= 4 ? EMAX / 4 : 1), LOGT>(tid);
-        else if (n <= THREADS * (EMAX / 2))
-            row.template expand_and_sort<EMAX / 2, LOGT>(tid);
+        if (n <= THREADS)
+            row.template expand_and_sort<1, LOGT>(tid);
+        else if (n <= THREADS * 2)
+            row.template expand_and_sort<2, LOGT>(tid);
+        else if (n <= THREADS * 4)
+            row.template expand_and_sort<4, LOGT>(tid);
         else
-            row.template expand_and_sort<EMAX, LOGT>(tid);
+            row.template expand_and_sort<8, LOGT>(tid);
         // stream out: sorted pairs, and per distinct tile column (C tile) its column + first pair
         int base = 0;
         for (int s0 = 0; s0 < n; s0 += THREADS) {
@@ -406,7 +408,10 @@ __global__ void __launch_bounds__(256) s1_compact_kernel(const int *__restrict__
                                                          const int *__restrict__ scratch_col, const int *__restrict__ scratch_off, int npairs,
                                                          int *__restrict__ c_rowidx, int *__restrict__ c_colidx, int *__restrict__ pairs_offset)
 {
+    constexpr int WCAP = 256;
     __shared__ int win[2];
+    __shared__ int wrp[WCAP + 1];   // c_rowptr of the rows this block's tiles fall into
+    __shared__ int wp0[WCAP];       // first pair of those rows
     const long long tb = (long long)blockIdx.x * blockDim.x;
     // the block's 256 consecutive tiles span few tile rows: two full searches bound the window
     if (threadIdx.x < 2) {
@@ -419,16 +424,35 @@ __global__ void __launch_bounds__(256) s1_compact_kernel(const int *__restrict__
         win[threadIdx.x] = lo;
     }
     __syncthreads();
+    const int w0 = win[0], w1 = win[1], nw = w1 - w0 + 1;
+    const bool cached = nw <= WCAP;
+    if (cached) {
+        for (int x = threadIdx.x; x <= nw; x += 256) wrp[x] = c_rowptr[w0 + x];
+        for (int x = threadIdx.x; x < nw; x += 256) wp0[x] = aprod_off[a_tile_rowptr[tr_lo + w0 + x] - a_lo];
+    }
+    __syncthreads();
     const long long t = tb + threadIdx.x;
     if (t >= ntc) return;
-    int lo = win[0], hi = win[1] + 1;
-    while (hi - lo > 1) {
-        int mid = (lo + hi) >> 1;
-        if (c_rowptr[mid] <= (int)t) lo = mid; else hi = mid;
+    int i, r, p0;
+    if (cached) {
+        int lo = 0, hi = nw;
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (wrp[mid] <= (int)t) lo = mid; else hi = mid;
+        }
+        i = w0 + lo;
+        r = (int)t - wrp[lo];
+        p0 = wp0[lo];
+    } else {
+        int lo = w0, hi = w1 + 1;
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (c_rowptr[mid] <= (int)t) lo = mid; else hi = mid;
+        }
+        i = lo;
+        r = (int)t - c_rowptr[i];
+        p0 = aprod_off[a_tile_rowptr[tr_lo + i] - a_lo];
     }
-    const int i = lo;
-    const int r = (int)t - c_rowptr[i];
-    const int p0 = aprod_off[a_tile_rowptr[tr_lo + i] - a_lo];
     c_rowidx[t] = i + tr_lo;
     c_colidx[t] = scratch_col[p0 + r];
     pairs_offset[t] = p0 + scratch_off[p0 + r];
@@ -568,29 +592,35 @@ __global__ void __launch_bounds__(256) s2_cmask_wide_kernel(const int *__restric
                                                             uint32_t *__restrict__ c_mask, int *__restrict__ c_tile_nnz,
                                                             uint8_t *__restrict__ c_rowptr)
 {
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // B's 16 row masks of the lane's current pair, [dword q][lane]: a lane only ever reads what it
+    // wrote itself (same wave, program order), so no barrier is needed
+    __shared__ unsigned bl[8][256];
+    const int tid = threadIdx.x;
+    long long t = (long long)blockIdx.x * blockDim.x + tid;
     if (t >= ntc) return;
     const int p0 = pairs_offset[t], p1 = pairs_offset[t + 1];
-    unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // natural layout: cw[q] = row 2q | row 2q+1 << 16
     for (int p = p0; p < p1; ++p) {
         const int a = pairs_a[p], b = pairs_b[p];
         const uint4 A0 = *reinterpret_cast<const uint4 *>(a_masks + 16 * (size_t)a);
         const uint4 A1 = *reinterpret_cast<const uint4 *>(a_masks + 16 * (size_t)a + 8);
         const uint4 B0 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)b);
         const uint4 B1 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)b + 8);
+        bl[0][tid] = B0.x; bl[1][tid] = B0.y; bl[2][tid] = B0.z; bl[3][tid] = B0.w;
+        bl[4][tid] = B1.x; bl[5][tid] = B1.y; bl[6][tid] = B1.z; bl[7][tid] = B1.w;
         const unsigned aw[8] = {A0.x, A0.y, A0.z, A0.w, A1.x, A1.y, A1.z, A1.w};
-        const unsigned bw[8] = {B0.x, B0.y, B0.z, B0.w, B1.x, B1.y, B1.z, B1.w};
-        unsigned bk[16];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            bk[2 * q] = bw[q] & 0xFFFFu;
-            bk[2 * q + 1] = bw[q] >> 16;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
+            unsigned am = aw[q];            // bits 0-15: row 2q, bits 16-31: row 2q+1
             unsigned acc = 0;
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) acc |= __umul24((aw[q] >> kk) & 0x00010001u, bk[kk]);
+            while (am) {                    // one iteration per nonzero of A in these two rows
+                const int bit = __builtin_ctz(am);
+                am &= am - 1;
+                const int kk = bit & 15;
+                const unsigned bwd = bl[kk >> 1][tid];            // rows kk&~1 (low half) and kk|1 (high half)
+                const unsigned brow = (kk & 1) ? (bwd >> 16) : (bwd & 0xFFFFu);
+                acc |= brow << (bit & 16);
+            }
             cw[q] |= acc;
         }
     }
@@ -893,8 +923,8 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
                          p->pairs_b.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->c_tile_rowptr.as<int>());       \
     }
     PEM_ROWSORT(2, 8192, 13, 1024, 2048, 1 << 20)
-    PEM_ROWSORT(1, 1024, 10, 256, 1024, 1 << 20)
-    PEM_ROWSORT(0, 128, 7, 64, 128, 1 << 20)
+    PEM_ROWSORT(1, 2048, 11, 256, 1024, 1 << 20)
+    PEM_ROWSORT(0, 512, 9, 64, 256, 1 << 20)
 #undef PEM_ROWSORT
 }
 
