@@ -403,60 +403,26 @@ __global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint3
 }
 
 // row-local scratch -> reference layout (_C_tileRowIdx/_C_tileColIdx, spgemm.cu:378-379; pair offsets :484)
+// One wave per tile row: the row knows where its tiles go (c_rowptr[i]) and where its scratch
+// lives (its first pair), so the copy is two coalesced streams and needs no search.
 __global__ void __launch_bounds__(256) s1_compact_kernel(const int *__restrict__ c_rowptr, int mt, long long ntc, int tr_lo,
                                                          const int *__restrict__ a_tile_rowptr, int a_lo, const int *__restrict__ aprod_off,
                                                          const int *__restrict__ scratch_col, const int *__restrict__ scratch_off, int npairs,
                                                          int *__restrict__ c_rowidx, int *__restrict__ c_colidx, int *__restrict__ pairs_offset)
 {
-    constexpr int WCAP = 256;
-    __shared__ int win[2];
-    __shared__ int wrp[WCAP + 1];   // c_rowptr of the rows this block's tiles fall into
-    __shared__ int wp0[WCAP];       // first pair of those rows
-    const long long tb = (long long)blockIdx.x * blockDim.x;
-    // the block's 256 consecutive tiles span few tile rows: two full searches bound the window
-    if (threadIdx.x < 2) {
-        long long tt = threadIdx.x == 0 ? tb : (tb + 255 < ntc ? tb + 255 : ntc - 1);
-        int lo = 0, hi = mt;   // largest i in [0, mt) with c_rowptr[i] <= tt
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (c_rowptr[mid] <= (int)tt) lo = mid; else hi = mid;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave; i < mt; i += nwaves) {
+        const int t0 = c_rowptr[i], cnt = c_rowptr[i + 1] - t0;
+        if (cnt == 0) continue;
+        const int p0 = aprod_off[a_tile_rowptr[tr_lo + i] - a_lo];
+        for (int r = lane; r < cnt; r += 64) {
+            c_rowidx[t0 + r] = i + tr_lo;
+            c_colidx[t0 + r] = scratch_col[p0 + r];
+            pairs_offset[t0 + r] = p0 + scratch_off[p0 + r];
         }
-        win[threadIdx.x] = lo;
     }
-    __syncthreads();
-    const int w0 = win[0], w1 = win[1], nw = w1 - w0 + 1;
-    const bool cached = nw <= WCAP;
-    if (cached) {
-        for (int x = threadIdx.x; x <= nw; x += 256) wrp[x] = c_rowptr[w0 + x];
-        for (int x = threadIdx.x; x < nw; x += 256) wp0[x] = aprod_off[a_tile_rowptr[tr_lo + w0 + x] - a_lo];
-    }
-    __syncthreads();
-    const long long t = tb + threadIdx.x;
-    if (t >= ntc) return;
-    int i, r, p0;
-    if (cached) {
-        int lo = 0, hi = nw;
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (wrp[mid] <= (int)t) lo = mid; else hi = mid;
-        }
-        i = w0 + lo;
-        r = (int)t - wrp[lo];
-        p0 = wp0[lo];
-    } else {
-        int lo = w0, hi = w1 + 1;
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (c_rowptr[mid] <= (int)t) lo = mid; else hi = mid;
-        }
-        i = lo;
-        r = (int)t - c_rowptr[i];
-        p0 = aprod_off[a_tile_rowptr[tr_lo + i] - a_lo];
-    }
-    c_rowidx[t] = i + tr_lo;
-    c_colidx[t] = scratch_col[p0 + r];
-    pairs_offset[t] = p0 + scratch_off[p0 + r];
-    if (t == ntc - 1) pairs_offset[ntc] = npairs;
+    if (blockIdx.x == 0 && threadIdx.x == 0) pairs_offset[ntc] = npairs;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1011,7 +977,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->c_tile_rowidx.reserve(sizeof(int) * (ntc + 4)));
         PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
         PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
-        PEM_LAUNCH(ctx, s1_compact_kernel, grid_for(ntc, 256), 256, p->c_tile_rowptr.as<int>(), mt, (long long)TC, p->tr_lo,
+        PEM_LAUNCH(ctx, s1_compact_kernel, grid_for((size_t)mt * 64, 256), 256, p->c_tile_rowptr.as<int>(), mt, (long long)TC, p->tr_lo,
                    A->tile_rowptr.as<int>(), p->a_lo, p->aprod_off.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), (int)P,
                    p->c_tile_rowidx.as<int>(), p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>());
         p->pairs_ready = true;
