@@ -38,7 +38,11 @@ def kernel_alg_bytes(name, d):
         "s2_cmask_kernel": 8 * P + 32 * TA + 32 * TB + 36 * TC,
         "s2_crowcol_kernel": 36 * TC + 16 * TC + NZ,
         "s3_accumulate_kernel": 8 * P + 8 * TC + NZ + (8 * nA + 52 * TA) + (8 * nB + 84 * TB) + 8 * NZ,
-        "s12_row_kernel": 8 * P + 8 * TA + 8 * TB + 12 * TC,
+        "s2_cmask_wide_kernel": 8 * P + 32 * TA + 32 * TB + 52 * TC,
+        "s2_crowcol_wide_kernel": 36 * TC + NZ,
+        "s3_accumulate_wide_kernel": 8 * P + 8 * TC + NZ + (8 * nA + 68 * TA) + (8 * nB + 100 * TB) + 8 * NZ,
+        "s1_rowsort_kernel<512>": None, "s1_rowsort_kernel<2048>": None, "s1_rowsort_kernel<8192>": None,
+        "s1_compact_kernel": 20 * TC,
     }
     return table.get(name)
 
@@ -66,13 +70,19 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the product path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; PEM_DIST_BACKEND=gloo lets several ranks rehearse the N>1 path on ONE card
+    backend = os.environ.get("PEM_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     pkg = graft.load_package()
     standins = importlib.import_module("pem_spgemm_amd.standins")
@@ -86,7 +96,7 @@ def main():
     # inputs resident in HBM before anything is timed
     dI, dJ, dV = torch.from_numpy(I).to(dev), torch.from_numpy(J).to(dev), torch.from_numpy(V).to(dev)
     torch.cuda.synchronize()
-    ctx = pkg.Context(local_rank)
+    ctx = pkg.Context(dev_index)
     A = pkg.Tiled.from_coo_device(ctx, rows, cols, len(I), dI.data_ptr(), dJ.data_ptr(), dV.data_ptr(), False)
     B = pkg.Tiled.from_coo_device(ctx, rows, cols, len(I), dI.data_ptr(), dJ.data_ptr(), dV.data_ptr(), True) if aat else A
     del dI, dJ, dV
@@ -150,8 +160,15 @@ def main():
     if dom is not None:
         ab = kernel_alg_bytes(dom, dims)
         ach = (ab / (kern[dom]["avg_ms"] * 1e-3) / 1e9) if ab else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # written by tools/pmc_summary.py from separate --pmc passes
+        if os.path.exists(tpath) and args.workload == "webbase-1M" and args.scale == 1.0 and world == 1:
+            try:
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         roofline = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=(ach / HBM_PEAK_GBS) if ach else None,
-                        traffic=None, alg_bytes_per_launch=ab, avg_launch_ms=kern[dom]["avg_ms"],
+                        traffic=traffic, alg_bytes_per_launch=ab, avg_launch_ms=kern[dom]["avg_ms"],
                         launches_per_step=kern[dom]["calls_per_step"])
 
     # whole-pipeline figure against SURVEY 8(d)'s B_alg (this rank's slice at N>1)

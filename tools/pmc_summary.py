@@ -36,3 +36,13 @@ for k, cs in per.items():
     rows.append((d * len(dur.get(k, [])), k, n, d, avg))
 for _, k, n, d, avg in sorted(rows, reverse=True):
     print(k[:34].ljust(34), str(len(dur.get(k, []))).rjust(5), f"{d:9.1f}", " ".join(f"{avg[c]:14.4g}" for c in cols))
+
+# machine-readable traffic per launch (FETCH corrected x2 + WRITE), consumed by bench.py's roofline.traffic
+import json
+traffic = {}
+for _, k, n, d, avg in rows:
+    f, w = avg["FETCH_SIZE"], avg["WRITE_SIZE"]
+    if f == f and w == w:
+        traffic[k.strip()] = dict(hbm_bytes_per_launch=f + w, fetch_bytes=f, write_bytes=w, avg_us=d)
+with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
+    json.dump(traffic, fh, indent=1, sort_keys=True)
