@@ -93,6 +93,9 @@ struct pem_ctx {
     pem::DevBuf tmp[12];               // step/convert temporaries, see call sites
     // timing
     hipEvent_t ev[8] = {};             // step spans
+    // fork/join inside a step: an independent long-tailed kernel runs on an auxiliary stream
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     pem_timings timings = {};
     bool profiling = false;
     std::vector<pem::KernelStat> stats;

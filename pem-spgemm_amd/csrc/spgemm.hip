@@ -104,10 +104,10 @@ __global__ void s1_c_rowptr_kernel(const int *__restrict__ c_rowidx, long long n
 // offsets go to row-local scratch (a row has at most as many C tiles as products) and are
 // compacted into the reference layout once the per-row tile counts have been scanned.
 // ------------------------------------------------------------------------------------------
-constexpr int S1_CAP0 = 512, S1_CAP1 = 2048, S1_CAP2 = 8192;
+constexpr int S1_CAP0 = 512, S1_CAP1 = 2048, S1_CAP2 = 8192, S1_CAP3 = 32768;
 
 __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int mt, int a_lo,
-                                                          const int *__restrict__ aprod_off, int *__restrict__ row_list,
+                                                          const int *__restrict__ aprod_off, int cap3, int *__restrict__ row_list,
                                                           int *__restrict__ bin_count, int *__restrict__ xl_base, int *__restrict__ row_tc)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
         xl_base[i] = -1;
         row_tc[i] = 0;
     }
-    const int bin = n == 0 ? -1 : n <= S1_CAP0 ? 0 : n <= S1_CAP1 ? 1 : n <= S1_CAP2 ? 2 : 3;
+    const int bin = n == 0 ? -1 : n <= S1_CAP0 ? 0 : n <= S1_CAP1 ? 1 : n <= S1_CAP2 ? 2 : n <= cap3 ? 3 : 4;
     // one atomic per wave and bin: ballot + prefix popcount hand out the slots (order is irrelevant)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
         base = __shfl(base, leader, 64);
         if (bin == b) row_list[(size_t)b * mt + base + __popcll(m & lt)] = i;
     }
-    if (bin == 3) xl_base[i] = atomicAdd(&bin_count[4], n);   // oversized rows are few
+    if (bin == 4) xl_base[i] = atomicAdd(&bin_count[5], n);   // oversized rows are few
 }
 
 // largest a in [lo, hi) with off[a] <= x
@@ -158,7 +158,7 @@ template <> __device__ __forceinline__ uint64_t s1_shfl_xor<uint64_t>(uint64_t v
 template <typename KeyT, int THREADS, int EPT, int LOGT>
 __device__ __forceinline__ void s1_bitonic_regs(KeyT (&v)[EPT], KeyT *lds, const int tid)
 {
-    constexpr int LOGE = EPT == 1 ? 0 : EPT == 2 ? 1 : EPT == 4 ? 2 : EPT == 8 ? 3 : 4;
+    constexpr int LOGE = EPT == 1 ? 0 : EPT == 2 ? 1 : EPT == 4 ? 2 : EPT == 8 ? 3 : EPT == 16 ? 4 : 5;
     constexpr int LOGNP = LOGT + LOGE;
 #pragma unroll
     for (int lk = 1; lk <= LOGNP; ++lk) {
@@ -230,6 +230,36 @@ struct S1Row {
         *a_out = a_lo + ar;
         return b;
     }
+    // more than 8 keys per thread: keep the keys in LDS (a register-resident sort of 16-32 keys per thread spills)
+    __device__ __forceinline__ void expand_and_sort_lds(const int tid) const
+    {
+        int npad = 2;
+        while (npad < n) npad <<= 1;
+        for (int q = tid; q < npad; q += THREADS) {
+            KeyT key = ~KeyT(0);
+            if (q < n) {
+                int a;
+                const int b = tile_b(q, &a);
+                key = (KeyT(b_tile_colidx[b]) << QB) | KeyT(q);
+            }
+            keys[q] = key;
+        }
+        __syncthreads();
+        for (int kk = 2; kk <= npad; kk <<= 1) {
+            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+                for (int t = tid; t < (npad >> 1); t += THREADS) {
+                    const int lo = 2 * t - (t & (jj - 1)), hi = lo + jj;
+                    const bool up = (lo & kk) == 0;
+                    const KeyT x = keys[lo], y = keys[hi];
+                    if ((x > y) == up) {
+                        keys[lo] = y;
+                        keys[hi] = x;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
     template <int EPT, int LOGT> __device__ __forceinline__ void expand_and_sort(const int tid) const
     {
         KeyT v[EPT];
@@ -249,7 +279,7 @@ struct S1Row {
 };
 
 template <typename KeyT, int CAP, int QB, int THREADS, int RCAP>
-__global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr,
+__global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8) : 1) s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr,
                                                              int tr_lo, int a_lo, const int *__restrict__ a_tile_colidx,
                                                              const int *__restrict__ aprod_off, const int *__restrict__ b_tile_rowptr,
                                                              const int *__restrict__ b_tile_colidx, int *__restrict__ pairs_a,
@@ -258,7 +288,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) s1_rowsort_k
 {
     constexpr int LOGT = THREADS == 64 ? 6 : THREADS == 256 ? 8 : 10;
     constexpr int EMAX = CAP / THREADS;
-    static_assert(EMAX == 8, "each bin sorts up to 8 keys per thread");
+    static_assert(EMAX == 8 || EMAX == 32, "a bin sorts up to 8 (or, for the largest, 32) keys per thread");
     __shared__ KeyT keys[CAP];
     __shared__ int roff[RCAP + 1];     // product offset of every A tile of the row, relative to the row
     __shared__ int rbs[RCAP];          // first B tile id of that A tile's B tile row
@@ -298,8 +328,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? 8 : 1) s1_rowsort_k
             row.template expand_and_sort<2, LOGT>(tid);
         else if (n <= THREADS * 4)
             row.template expand_and_sort<4, LOGT>(tid);
-        else
+        else if (EMAX == 8 || n <= THREADS * 8)
             row.template expand_and_sort<8, LOGT>(tid);
+        else
+            row.expand_and_sort_lds(tid);
         // stream out: sorted pairs, and per distinct tile column (C tile) its column + first pair
         int base = 0;
         for (int s0 = 0; s0 < n; s0 += THREADS) {
@@ -876,7 +908,7 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
 }
 
 template <typename KeyT>
-static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int mt)
+static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int mt, int cap3)
 {
     const pem_tiled *A = p->A, *B = p->B;
     int *rl = p->row_list.as<int>();
@@ -888,10 +920,26 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
                          p->aprod_off.as<int>(), B->tile_rowptr.as<int>(), B->tile_colidx.as<int>(), p->pairs_a.as<int>(),             \
                          p->pairs_b.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->c_tile_rowptr.as<int>());       \
     }
+    // The largest bin is a handful of rows, one 1024-thread block per CU, each running long: fork it onto the
+    // auxiliary stream so the other bins fill the rest of the chip meanwhile; joined before the row-count scan.
+    bool forked = false;
+    if constexpr (sizeof(KeyT) == 4) {
+        if (cap3 > S1_CAP2 && counts[3] > 0) {
+            hipStream_t main_stream = ctx->stream;
+            (void)hipEventRecord(ctx->ev_fork, main_stream);
+            (void)hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0);
+            ctx->stream = ctx->aux;
+            PEM_ROWSORT(3, 32768, 15, 1024, 2048, 1 << 20)
+            (void)hipEventRecord(ctx->ev_join, ctx->aux);
+            ctx->stream = main_stream;
+            forked = true;
+        }
+    }
     PEM_ROWSORT(2, 8192, 13, 1024, 2048, 1 << 20)
     PEM_ROWSORT(1, 2048, 11, 256, 1024, 1 << 20)
     PEM_ROWSORT(0, 512, 9, 64, 256, 1 << 20)
 #undef PEM_ROWSORT
+    if (forked) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
 }
 
 static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
@@ -900,6 +948,8 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     hipStream_t st = ctx->stream;
     const int nA = p->a_hi - p->a_lo, mt = p->tr_hi - p->tr_lo;
     const int bits_tc = bits_for((uint64_t)B->tile_cols), bits_row = bits_for((uint64_t)(mt > 0 ? mt : 1));
+    // the 32768-key LDS bin needs 32-bit keys (tile col + 15 index bits); wider B goes to the global path above 8192
+    const int cap3 = bits_tc + 15 <= 32 ? S1_CAP3 : S1_CAP2;
     p->state = 0;
     p->pairs_ready = false;
     p->ntiles_c = p->npairs = p->nnz_c = 0;
@@ -907,7 +957,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     PEM_HIP(hipEventRecord(ctx->ev[0], st));
     PEM_TRY(p->aprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
     PEM_TRY(p->c_tile_rowptr.reserve(sizeof(int) * ((size_t)mt + 4)));
-    PEM_TRY(p->row_list.reserve(sizeof(int) * (4 * (size_t)mt + 4)));
+    PEM_TRY(p->row_list.reserve(sizeof(int) * (5 * (size_t)mt + 4)));
     PEM_TRY(p->bin_count.reserve(sizeof(int) * 8));
     PEM_TRY(p->xl_base.reserve(sizeof(int) * ((size_t)mt + 4)));
     PEM_TRY(p->pairs_offset.reserve(sizeof(int) * 4));
@@ -921,14 +971,14 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     // per-row tile counts are accumulated in c_tile_rowptr and scanned in place afterwards
     if (mt > 0)
         PEM_LAUNCH(ctx, s1_rowclass_kernel, grid_for((size_t)mt, 256), 256, A->tile_rowptr.as<int>(), p->tr_lo, mt, p->a_lo,
-                   p->aprod_off.as<int>(), p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(), p->c_tile_rowptr.as<int>());
+                   p->aprod_off.as<int>(), cap3, p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(), p->c_tile_rowptr.as<int>());
     // one read-back: P, the bin populations and the product total of the oversized rows
     int64_t P = 0;
     int *hb = reinterpret_cast<int *>(ctx->h_scalars + 32);
     PEM_HIP(hipMemcpyAsync(hb, p->bin_count.p, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
     PEM_TRY(read_scalars(ctx, ctx->d_scalars, 1, &P));
     int counts[4] = {hb[0], hb[1], hb[2], hb[3]};
-    const size_t n_xl = (size_t)hb[4];
+    const size_t n_xl = (size_t)hb[5];
     if (P > 0x7FFFFFFFll) {
         set_error("step 1: %lld tile pairs exceed the int32 range of the reference's pair arrays", (long long)P);
         return PEM_E_OVERFLOW;
@@ -942,9 +992,9 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->scratch_col.reserve(sizeof(int) * (n + 4)));
         PEM_TRY(p->scratch_off.reserve(sizeof(int) * (n + 4)));
         if (bits_tc + 13 <= 32)
-            launch_rowsorts<uint32_t>(ctx, p, counts, mt);
+            launch_rowsorts<uint32_t>(ctx, p, counts, mt, cap3);
         else
-            launch_rowsorts<uint64_t>(ctx, p, counts, mt);
+            launch_rowsorts<uint64_t>(ctx, p, counts, mt, cap3);
         if (n_xl > 0) {   // oversized rows: global expand + stable radix sort on (row, tile col)
             PEM_TRY(p->prod_a.reserve(sizeof(int) * n_xl));
             PEM_TRY(p->prod_b.reserve(sizeof(int) * n_xl));
