@@ -674,21 +674,47 @@ __global__ void __launch_bounds__(256) s2_crowcol_wide_kernel(const uint32_t *__
 // row record (mask | rowptr<<16), one of B's transposed mask; per product one B row record and
 // the two operand values.  Pairs ascend in k-tile, bits ascend, one fma per product: the same
 // chain as the oracle.
+constexpr int S3_EPW = 256;   // C entries per wave
 __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b, long long ntc,
-    const int *__restrict__ c_tile_nnz_ptr, const uint8_t *__restrict__ c_rowcolidx, double *__restrict__ c_vals,
+    const int *__restrict__ c_tile_nnz_ptr, long long nnz_c, const uint8_t *__restrict__ c_rowcolidx, double *__restrict__ c_vals,
     const int *__restrict__ a_nnz_ptr, const double *__restrict__ a_vals, const uint32_t *__restrict__ a_rec,
     const int *__restrict__ b_nnz_ptr, const double *__restrict__ b_vals, const uint32_t *__restrict__ b_rec,
     const uint16_t *__restrict__ b_masks_t)
 {
+    // Work is dealt by ENTRIES, S3_EPW per wave, so hub rows (tiles with many entries and pairs) cannot pile
+    // up in one wave.  The wave finds its first tile with a 64-ary search (one gather + ballot per level),
+    // then walks the tiles 64 at a time: their value offsets and pair ranges sit one per lane in registers,
+    // and the entry -> tile lookup is a 6-step shuffle search with no memory traffic.
     const int lane = threadIdx.x & 63;
-    const long long t0 = (((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) << 6;   // first tile of this wave
-    if (t0 >= ntc) return;
-    const long long tl = t0 + lane < ntc ? t0 + lane : ntc - 1;
-    const int my_off = (t0 + lane < ntc) ? c_tile_nnz_ptr[tl] : 0x7FFFFFFF;   // value offset of tile t0+lane
-    const int my_p0 = pairs_offset[tl], my_p1 = pairs_offset[tl + 1];
-    const long long tend = t0 + 64 < ntc ? t0 + 64 : ntc;
-    const int e_begin = __shfl(my_off, 0, 64), e_end = c_tile_nnz_ptr[tend];
+    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long eb = wave * S3_EPW;
+    if (eb >= nnz_c) return;
+    const int e_lo = (int)eb, e_hi = (int)(eb + S3_EPW < nnz_c ? eb + S3_EPW : nnz_c);
+    // largest tile t with c_tile_nnz_ptr[t] <= e_lo
+    long long lo = 0, hi = ntc;   // invariant: ptr[lo] <= e_lo, answer in [lo, hi)
+    while (hi - lo > 64) {
+        const long long step = (hi - lo + 63) >> 6;
+        const long long idx = lo + lane * step;
+        const bool le = idx < hi && c_tile_nnz_ptr[idx] <= e_lo;
+        const int k = __popcll(__ballot(le));          // monotone: the first k probes are <= e_lo (k >= 1)
+        const long long nlo = lo + (long long)(k - 1) * step;
+        hi = nlo + step < hi ? nlo + step : hi;
+        lo = nlo;
+    }
+    {
+        const bool le = lo + lane < hi && c_tile_nnz_ptr[lo + lane] <= e_lo;
+        lo += __popcll(__ballot(le)) - 1;
+    }
+    for (long long t0 = lo; t0 < ntc; t0 += 64) {
+        const long long tl = t0 + lane < ntc ? t0 + lane : ntc - 1;
+        const int my_off = (t0 + lane < ntc) ? c_tile_nnz_ptr[tl] : 0x7FFFFFFF;   // value offset of tile t0+lane
+        const int my_p0 = pairs_offset[tl], my_p1 = pairs_offset[tl + 1];
+        const long long tend = t0 + 64 < ntc ? t0 + 64 : ntc;
+        const int chunk_end = c_tile_nnz_ptr[tend];
+        const int first = __shfl(my_off, 0, 64);
+        if (first >= e_hi) break;
+        const int e_begin = first > e_lo ? first : e_lo, e_end = chunk_end < e_hi ? chunk_end : e_hi;
     for (int ebase = e_begin; ebase < e_end; ebase += 64) {   // wave-uniform trip count: every lane stays live for the shuffles
         const int e = ebase + lane;
         const bool valid = e < e_end;
@@ -723,6 +749,8 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
             }
         }
         c_vals[e] = acc;
+    }
+        if (chunk_end >= e_hi) break;
     }
 }
 
@@ -1110,8 +1138,9 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
     const char *wide_env = getenv("PEM_WIDE");
     const bool wide = !(wide_env && !strcmp(wide_env, "0"));
     if (ntc > 0 && wide)
-        PEM_LAUNCH(ctx, s3_accumulate_wide_kernel, grid_for(ntc, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
-                   (long long)ntc, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<double>(), A->tile_nnz_ptr.as<int>(),
+        PEM_LAUNCH(ctx, s3_accumulate_wide_kernel, grid_for(((size_t)p->nnz_c + S3_EPW - 1) / S3_EPW * 64, 256), 256, p->pairs_offset.as<int>(),
+                   p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(), (long long)p->nnz_c,
+                   p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<double>(), A->tile_nnz_ptr.as<int>(),
                    A->vals.as<double>(), A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals.as<double>(), B->tile_rec.as<uint32_t>(),
                    B->masks_t.as<uint16_t>());
     else if (ntc > 0)
