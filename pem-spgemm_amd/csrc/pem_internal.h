@@ -186,4 +186,10 @@ struct pem_cplan {
     // row-local step 1
     pem::DevBuf row_list, bin_count, xl_base, xl_rowstart, scratch_col, scratch_off;
     bool pairs_ready = false;          // step 1 already wrote pairs_a / pairs_b
+    // sizes of the last complete pass on this plan.  A and B are immutable, so a repeat pass has the same
+    // sizes: it skips the three host read-backs and a device-side check compares them at the end instead.
+    bool warm = false, warm_pass = false;
+    int64_t w_P = 0, w_TC = 0, w_nnz = 0;
+    int w_counts[4] = {0, 0, 0, 0};
+    int64_t w_nxl = 0;
 };

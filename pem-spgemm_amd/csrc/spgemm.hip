@@ -814,6 +814,16 @@ __global__ void split_rowprod_kernel(const int *__restrict__ a_tile_rowptr, cons
     rowprod[i] = s;
 }
 
+
+// repeat pass on an unchanged plan: the sizes the host assumed (from the previous pass) against what this pass computed
+__global__ void warm_verify_kernel(const long long *__restrict__ d_scalars, const int *__restrict__ bin_count, long long P, long long TC,
+                                   long long nnz, int c0, int c1, int c2, int c3, long long nxl, int *__restrict__ flags)
+{
+    if (d_scalars[0] != P || d_scalars[1] != TC || d_scalars[2] != nnz || bin_count[0] != c0 || bin_count[1] != c1 || bin_count[2] != c2 ||
+        bin_count[3] != c3 || bin_count[5] != nxl)
+        flags[FLAG_CAPACITY] = 1;
+}
+
 // ------------------------------------------------------------------------------------------
 // host drivers
 // ------------------------------------------------------------------------------------------
@@ -990,6 +1000,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     PEM_TRY(p->xl_base.reserve(sizeof(int) * ((size_t)mt + 4)));
     PEM_TRY(p->pairs_offset.reserve(sizeof(int) * 4));
     PEM_HIP(hipMemsetAsync(p->bin_count.p, 0, sizeof(int) * 8, st));
+    PEM_HIP(hipMemsetAsync(ctx->d_scalars, 0, sizeof(int64_t) * 3, st));   // P, T_C, C_nnz of this pass
     PEM_HIP(hipMemsetAsync(p->c_tile_rowptr.p, 0, sizeof(int) * ((size_t)mt + 1), st));
     PEM_HIP(hipMemsetAsync(p->pairs_offset.p, 0, sizeof(int), st));
     if (nA > 0)
@@ -1002,11 +1013,21 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
                    p->aprod_off.as<int>(), cap3, p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(), p->c_tile_rowptr.as<int>());
     // one read-back: P, the bin populations and the product total of the oversized rows
     int64_t P = 0;
-    int *hb = reinterpret_cast<int *>(ctx->h_scalars + 32);
-    PEM_HIP(hipMemcpyAsync(hb, p->bin_count.p, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
-    PEM_TRY(read_scalars(ctx, ctx->d_scalars, 1, &P));
-    int counts[4] = {hb[0], hb[1], hb[2], hb[3]};
-    const size_t n_xl = (size_t)hb[5];
+    int counts[4];
+    size_t n_xl;
+    if (p->warm_pass) {
+        P = p->w_P;
+        for (int b = 0; b < 4; ++b) counts[b] = p->w_counts[b];
+        n_xl = (size_t)p->w_nxl;
+    } else {
+        int *hb = reinterpret_cast<int *>(ctx->h_scalars + 32);
+        PEM_HIP(hipMemcpyAsync(hb, p->bin_count.p, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
+        PEM_TRY(read_scalars(ctx, ctx->d_scalars, 1, &P));
+        for (int b = 0; b < 4; ++b) counts[b] = p->w_counts[b] = hb[b];
+        n_xl = (size_t)hb[5];
+        p->w_nxl = (int64_t)n_xl;
+        p->w_P = P;
+    }
     if (P > 0x7FFFFFFFll) {
         set_error("step 1: %lld tile pairs exceed the int32 range of the reference's pair arrays", (long long)P);
         return PEM_E_OVERFLOW;
@@ -1050,7 +1071,12 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         }
         // _C_rowPtr = exclusive scan of the per-row tile counts (spgemm.cu:1168); total = T_C
         PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_rowptr.as<int>(), p->c_tile_rowptr.as<int>(), (size_t)mt, ctx->d_scalars + 1));
-        PEM_TRY(read_scalars(ctx, ctx->d_scalars + 1, 1, &TC));
+        if (p->warm_pass) {
+            TC = p->w_TC;
+        } else {
+            PEM_TRY(read_scalars(ctx, ctx->d_scalars + 1, 1, &TC));
+            p->w_TC = TC;
+        }
         const size_t ntc = (size_t)TC;
         PEM_TRY(p->c_tile_rowidx.reserve(sizeof(int) * (ntc + 4)));
         PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
@@ -1066,10 +1092,16 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     return PEM_OK;
 }
 
-static pem_status step1_impl(pem_ctx *ctx, pem_cplan *p)
+static pem_status step1_impl(pem_ctx *ctx, pem_cplan *p, bool allow_warm)
 {
     const char *mode = getenv("PEM_STEP1");
-    if (mode && !strcmp(mode, "esc")) return step1_esc_impl(ctx, p);
+    const char *nowarm = getenv("PEM_NO_WARM");
+    p->warm_pass = false;
+    if (mode && !strcmp(mode, "esc")) {
+        p->warm = false;
+        return step1_esc_impl(ctx, p);
+    }
+    p->warm_pass = allow_warm && p->warm && !(nowarm && !strcmp(nowarm, "1"));
     return step1_rows_impl(ctx, p);
 }
 
@@ -1104,7 +1136,12 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
     }
     PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_nnz_ptr.as<int>(), p->c_tile_nnz_ptr.as<int>(), ntc, ctx->d_scalars + 2));
     int64_t nnzc = 0;
-    PEM_TRY(read_scalars(ctx, ctx->d_scalars + 2, 1, &nnzc));
+    if (p->warm_pass) {
+        nnzc = p->w_nnz;
+    } else {
+        PEM_TRY(read_scalars(ctx, ctx->d_scalars + 2, 1, &nnzc));
+        p->w_nnz = nnzc;
+    }
     if (nnzc > 0x7FFFFFFFll) {
         set_error("step 2: C has %lld nonzeros, beyond the int32 range of the reference's offsets", (long long)nnzc);
         return PEM_E_OVERFLOW;
@@ -1157,7 +1194,7 @@ extern "C" pem_status pem_spgemm_step1(pem_ctx *ctx, pem_cplan *plan)
 {
     if (!ctx || !plan) return PEM_E_INVALID;
     PEM_HIP(hipSetDevice(ctx->device));
-    PEM_TRY(step1_impl(ctx, plan));
+    PEM_TRY(step1_impl(ctx, plan, false));   // step-wise calls always read the sizes back
     PEM_HIP(hipStreamSynchronize(ctx->stream));
     return step_elapsed(ctx, 0, &ctx->timings.step1_ms);
 }
@@ -1187,10 +1224,25 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
     if (!ctx || !plan) return PEM_E_INVALID;
     PEM_HIP(hipSetDevice(ctx->device));
     auto t0 = std::chrono::high_resolution_clock::now();
-    PEM_TRY(step1_impl(ctx, plan));
+    PEM_TRY(step1_impl(ctx, plan, true));
     PEM_TRY(step2_impl(ctx, plan));
     PEM_TRY(step3_impl(ctx, plan));
+    if (plan->warm_pass) {
+        // repeat pass: the host never waited for P / T_C / C_nnz; check on the device that they are what it assumed
+        PEM_LAUNCH(ctx, warm_verify_kernel, 1, 1, reinterpret_cast<const long long *>(ctx->d_scalars), plan->bin_count.as<int>(),
+                   (long long)plan->w_P, (long long)plan->w_TC, (long long)plan->w_nnz, plan->w_counts[0], plan->w_counts[1], plan->w_counts[2],
+                   plan->w_counts[3], (long long)plan->w_nxl, ctx->d_flags);
+        int hf[NUM_FLAGS];
+        PEM_TRY(read_flags(ctx, hf));   // the pass's one synchronisation
+        if (hf[FLAG_CAPACITY]) {        // cannot happen while A and B are immutable; recover by a full pass
+            plan->warm = false;
+            PEM_TRY(step1_impl(ctx, plan, false));
+            PEM_TRY(step2_impl(ctx, plan));
+            PEM_TRY(step3_impl(ctx, plan));
+        }
+    }
     PEM_HIP(hipStreamSynchronize(ctx->stream));
+    plan->warm = plan->pairs_ready && plan->state == 3;
     ctx->timings.spgemm_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
     PEM_TRY(step_elapsed(ctx, 0, &ctx->timings.step1_ms));
     PEM_TRY(step_elapsed(ctx, 2, &ctx->timings.step2_ms));

@@ -96,3 +96,25 @@ def test_narrow_step23_kernels_match(pkg, oracle, ctx, name, monkeypatch):
     op = oracle.Plan(oA, oB)
     for arr in C_NAMES:
         assert np.array_equal(plan.array(arr), getattr(op, arr)), f"{name}: plan array {arr} differs (narrow)"
+
+
+def test_repeat_passes_skip_readbacks_and_stay_identical(pkg, oracle, ctx, monkeypatch):
+    """pem_spgemm on an unchanged plan re-uses the sizes of the previous pass (no host read-backs, device-side
+    check); results must stay identical, also against a forced cold pass (PEM_NO_WARM=1)."""
+    from matgen import cases as _cases
+    for name in ("powerlaw_600", "hub_row_4000", "empty_matrix", "blockrows_10000"):
+        gA, gB, oA, oB = _tiled_pair(pkg, oracle, ctx, CASES[name])
+        plan = pkg.CPlan(ctx, gA, gB)
+        plan.spgemm()                      # cold
+        cold = [plan.array(a) for a in C_NAMES]
+        for _ in range(3):
+            plan.spgemm()                  # warm
+        warm = [plan.array(a) for a in C_NAMES]
+        monkeypatch.setenv("PEM_NO_WARM", "1")
+        plan.spgemm()
+        forced = [plan.array(a) for a in C_NAMES]
+        monkeypatch.delenv("PEM_NO_WARM")
+        op = oracle.Plan(oA, oB)
+        for a, c, w, f in zip(C_NAMES, cold, warm, forced):
+            want = getattr(op, a)
+            assert np.array_equal(c, want) and np.array_equal(w, want) and np.array_equal(f, want), (name, a)
