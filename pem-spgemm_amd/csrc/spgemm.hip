@@ -800,6 +800,144 @@ __global__ void __launch_bounds__(256) ex_fill_kernel(const int *__restrict__ c_
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// a14 export, balanced form (default).  CSR order inside a tile row is (row r, tile col, c), the tiled
+// order is (tile col, r, c): a stable 16-bucket partition per tile row.  Tile rows are cut into chunks
+// of 64 consecutive tiles, one wave per chunk, one tile per lane:
+//   ex_chunkhist  per chunk, the entry count of each of the 16 rows        (reads the 32-byte C masks)
+//   ex_chunkscan  per tile row, exclusive scan of its chunks' counts -> chunk bases, row totals
+//   (device scan of the row totals -> CSR row pointer)
+//   ex_chunkfill  per chunk: lane-exclusive prefix of the row counts by shuffles, then every lane
+//                 streams its tile's entries to rowptr[row] + chunk base + prefix
+// Neighbouring lanes hold neighbouring tiles of the same tile row, so their writes to a row abut.
+// ------------------------------------------------------------------------------------------
+__global__ void ex_chunkcount_kernel(const int *__restrict__ c_tile_rowptr, int mt, int *__restrict__ chunkcnt)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < mt) chunkcnt[i] = (c_tile_rowptr[i + 1] - c_tile_rowptr[i] + 63) >> 6;
+}
+
+// tile row of chunk ch: largest i in [0, mt) with chunkptr[i] <= ch, by a 64-ary search (one gather + ballot per level)
+__device__ __forceinline__ int ex_chunk_row(const int *__restrict__ chunkptr, int mt, int ch, int lane)
+{
+    int lo = 0, hi = mt;
+    while (hi - lo > 64) {
+        const int step = (hi - lo + 63) >> 6;
+        const int idx = lo + lane * step;
+        const bool le = idx < hi && chunkptr[idx] <= ch;
+        const int k = __popcll(__ballot(le));
+        const int nlo = lo + (k - 1) * step;
+        hi = nlo + step < hi ? nlo + step : hi;
+        lo = nlo;
+    }
+    const bool le = lo + lane < hi && chunkptr[lo + lane] <= ch;
+    return lo + __popcll(__ballot(le)) - 1;
+}
+
+// per-row entry counts of one C tile packed as 16-bit fields: p[j] holds rows 4j..4j+3 (a chunk sums to <= 1024 per row)
+__device__ __forceinline__ void ex_pack_counts(const uint4 M0, const uint4 M1, unsigned long long (&p)[4])
+{
+    const unsigned w[8] = {M0.x, M0.y, M0.z, M0.w, M1.x, M1.y, M1.z, M1.w};   // word q = (row 2q) << 16 | row 2q+1
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        p[j] = (unsigned long long)__popc(w[2 * j] >> 16) | ((unsigned long long)__popc(w[2 * j] & 0xFFFFu) << 16) |
+               ((unsigned long long)__popc(w[2 * j + 1] >> 16) << 32) | ((unsigned long long)__popc(w[2 * j + 1] & 0xFFFFu) << 48);
+}
+
+__global__ void __launch_bounds__(256) ex_chunkhist_kernel(const int *__restrict__ chunkptr, int mt, const int *__restrict__ c_tile_rowptr,
+                                                           const uint32_t *__restrict__ c_mask, int *__restrict__ chunkhist)
+{
+    const int lane = threadIdx.x & 63;
+    const int ch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (ch >= chunkptr[mt]) return;
+    const int i = ex_chunk_row(chunkptr, mt, ch, lane);
+    const int t0 = c_tile_rowptr[i] + ((ch - chunkptr[i]) << 6);
+    const int ntl = c_tile_rowptr[i + 1] - t0 < 64 ? c_tile_rowptr[i + 1] - t0 : 64;
+    unsigned long long pk[4] = {0, 0, 0, 0};
+    if (lane < ntl) {
+        const long long t = t0 + lane;
+        ex_pack_counts(*reinterpret_cast<const uint4 *>(c_mask + 8 * t), *reinterpret_cast<const uint4 *>(c_mask + 8 * t + 4), pk);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) pk[j] += __shfl_xor(pk[j], d, 64);
+    if (lane < 16) {
+        const unsigned long long sel = (lane >> 2) == 0 ? pk[0] : (lane >> 2) == 1 ? pk[1] : (lane >> 2) == 2 ? pk[2] : pk[3];
+        chunkhist[16 * (size_t)ch + lane] = (int)((sel >> (16 * (lane & 3))) & 0xFFFFull);
+    }
+}
+
+__global__ void __launch_bounds__(256) ex_chunkscan_kernel(const int *__restrict__ chunkptr, int mt, int nrows, int *__restrict__ chunkhist,
+                                                           int *__restrict__ rowcnt)
+{
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int r = threadIdx.x & 15;
+    if (i >= mt) return;
+    int run = 0;
+    for (int ch = chunkptr[i]; ch < chunkptr[i + 1]; ++ch) {
+        const int h = chunkhist[16 * (size_t)ch + r];
+        chunkhist[16 * (size_t)ch + r] = run;      // in place: count -> exclusive base inside the tile row
+        run += h;
+    }
+    if (16 * i + r < nrows) rowcnt[16 * i + r] = run;
+}
+
+__global__ void __launch_bounds__(256) ex_chunkfill_kernel(const int *__restrict__ chunkptr, int mt, int nrows, const int *__restrict__ c_tile_rowptr,
+                                                           const int *__restrict__ c_tile_colidx, const uint32_t *__restrict__ c_mask,
+                                                           const int *__restrict__ c_tile_nnz_ptr, const double *__restrict__ c_vals,
+                                                           const int *__restrict__ chunkbase, const int *__restrict__ rowptr,
+                                                           int *__restrict__ colidx, double *__restrict__ vals)
+{
+    const int lane = threadIdx.x & 63;
+    const int ch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (ch >= chunkptr[mt]) return;
+    const int i = ex_chunk_row(chunkptr, mt, ch, lane);
+    const int t0 = c_tile_rowptr[i] + ((ch - chunkptr[i]) << 6);
+    const int ntl = c_tile_rowptr[i + 1] - t0 < 64 ? c_tile_rowptr[i + 1] - t0 : 64;
+    const bool live = lane < ntl;
+    const long long t = t0 + (live ? lane : 0);
+    uint4 M0 = make_uint4(0, 0, 0, 0), M1 = M0;
+    if (live) {
+        M0 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t);
+        M1 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t + 4);
+    }
+    unsigned long long pk[4], inc[4];
+    ex_pack_counts(M0, M1, pk);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {          // inclusive scan over the lanes of the packed per-row counts
+        unsigned long long v = pk[j];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long u = __shfl_up(v, d, 64);
+            if (lane >= d) v += u;
+        }
+        inc[j] = v;
+    }
+    // lanes 0..15 fetch rowptr + chunk base of row r; every lane picks row r's value by shuffle
+    int rb = 0;
+    if (lane < 16 && 16 * i + lane < nrows) rb = rowptr[16 * i + lane] + chunkbase[16 * (size_t)ch + lane];
+    const unsigned w[8] = {M0.x, M0.y, M0.z, M0.w, M1.x, M1.y, M1.z, M1.w};
+    const int cbase = live ? (c_tile_colidx[t] << 4) : 0;
+    int src = live ? c_tile_nnz_ptr[t] : 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int base_r = __shfl(rb, r, 64);
+        const int excl = (int)(((inc[r >> 2] - pk[r >> 2]) >> (16 * (r & 3))) & 0xFFFFull);
+        int dst = base_r + excl;
+        unsigned m = (r & 1) ? (w[r >> 1] & 0xFFFFu) : (w[r >> 1] >> 16);
+        while (m) {
+            const int c = __builtin_ctz(m);
+            m &= m - 1;
+            colidx[dst] = cbase + c;
+            vals[dst] = c_vals[src];
+            ++dst;
+            ++src;
+        }
+    }
+}
+
 // per tile row of A: tile-level intermediate products (work estimate for the row-block split)
 __global__ void split_rowprod_kernel(const int *__restrict__ a_tile_rowptr, const int *__restrict__ a_tile_colidx,
                                      const int *__restrict__ b_tile_rowptr, int mt, long long *__restrict__ rowprod)
@@ -1301,13 +1439,30 @@ extern "C" pem_status pem_c_export_csr_device(pem_ctx *ctx, const pem_cplan *p, 
     const int nrows = r1 - r0;
     PEM_HIP(hipEventRecord(ctx->ev[6], st));
     PEM_HIP(hipMemsetAsync(d_rowptr, 0, sizeof(int) * ((size_t)nrows + 1), st));
-    if (mt > 0 && nrows > 0) {
+    const char *narrow = getenv("PEM_EXPORT");
+    if (mt > 0 && nrows > 0 && narrow && !strcmp(narrow, "rows")) {   // 16 lanes per tile row, serial over its tiles (A/B baseline)
         PEM_LAUNCH(ctx, ex_rowcount_kernel, grid_for((size_t)mt * 16, 256), 256, p->c_tile_rowptr.as<int>(), p->c_mask.as<uint16_t>(), mt, nrows,
                    d_rowptr);
         PEM_TRY(exclusive_scan_i32(ctx, d_rowptr, d_rowptr, (size_t)nrows, nullptr));
         if (p->nnz_c > 0)
             PEM_LAUNCH(ctx, ex_fill_kernel, grid_for((size_t)mt * 16, 256), 256, p->c_tile_rowptr.as<int>(), p->c_tile_colidx.as<int>(),
                        p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>(), p->c_rowptr.as<uint8_t>(), p->c_vals.as<double>(), mt, nrows,
+                       d_rowptr, d_colidx, d_vals);
+    } else if (mt > 0 && nrows > 0) {
+        const size_t maxchunks = (size_t)p->ntiles_c / 64 + (size_t)mt + 1;   // every tile row adds at most one partial chunk
+        DevBuf &chunkptr = ctx->tmp[4], &chunkhist = ctx->tmp[5];
+        PEM_TRY(chunkptr.reserve(sizeof(int) * ((size_t)mt + 4)));
+        PEM_TRY(chunkhist.reserve(sizeof(int) * 16 * (maxchunks + 1)));
+        PEM_LAUNCH(ctx, ex_chunkcount_kernel, grid_for((size_t)mt, 256), 256, p->c_tile_rowptr.as<int>(), mt, chunkptr.as<int>());
+        PEM_TRY(exclusive_scan_i32(ctx, chunkptr.as<int>(), chunkptr.as<int>(), (size_t)mt, nullptr));
+        if (p->ntiles_c > 0)
+            PEM_LAUNCH(ctx, ex_chunkhist_kernel, grid_for(maxchunks * 64, 256), 256, chunkptr.as<int>(), mt, p->c_tile_rowptr.as<int>(),
+                       p->c_mask.as<uint32_t>(), chunkhist.as<int>());
+        PEM_LAUNCH(ctx, ex_chunkscan_kernel, grid_for((size_t)mt * 16, 256), 256, chunkptr.as<int>(), mt, nrows, chunkhist.as<int>(), d_rowptr);
+        PEM_TRY(exclusive_scan_i32(ctx, d_rowptr, d_rowptr, (size_t)nrows, nullptr));
+        if (p->nnz_c > 0)
+            PEM_LAUNCH(ctx, ex_chunkfill_kernel, grid_for(maxchunks * 64, 256), 256, chunkptr.as<int>(), mt, nrows, p->c_tile_rowptr.as<int>(),
+                       p->c_tile_colidx.as<int>(), p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>(), p->c_vals.as<double>(), chunkhist.as<int>(),
                        d_rowptr, d_colidx, d_vals);
     }
     PEM_HIP(hipEventRecord(ctx->ev[7], st));

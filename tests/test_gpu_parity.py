@@ -118,3 +118,17 @@ def test_repeat_passes_skip_readbacks_and_stay_identical(pkg, oracle, ctx, monke
         for a, c, w, f in zip(C_NAMES, cold, warm, forced):
             want = getattr(op, a)
             assert np.array_equal(c, want) and np.array_equal(w, want) and np.array_equal(f, want), (name, a)
+
+
+@pytest.mark.parametrize("name", ["powerlaw_600", "hub_row_4000", "ragged_37", "empty_rows"])
+def test_row_serial_export_matches(pkg, oracle, ctx, name, monkeypatch):
+    """PEM_EXPORT=rows selects the 16-lanes-per-tile-row export (A/B baseline of the chunked export)."""
+    gA, gB, oA, oB = _tiled_pair(pkg, oracle, ctx, CASES[name])
+    plan = pkg.CPlan(ctx, gA, gB)
+    plan.spgemm()
+    fast = plan.export_csr()
+    monkeypatch.setenv("PEM_EXPORT", "rows")
+    slow = plan.export_csr()
+    want = oracle.Plan(oA, oB).export_csr()
+    for a, b, c in zip(fast, slow, want):
+        assert np.array_equal(a, c) and np.array_equal(b, c)
