@@ -109,35 +109,47 @@ def main():
     bufs = {}
 
     def step():
+        """the metric's unit: step1 + step2 + step3 on this rank's row block (spgemm.cu:1136-1341)"""
         plan.spgemm()
-        if gather:
-            info = plan.info()
-            nrows, nz = info["row_end"] - info["row_begin"], info["nnz_c"]
-            if bufs.get("nz") != nz:
-                bufs.update(nz=nz, rp=torch.empty(nrows + 1, dtype=torch.int32, device=dev),
-                            ci=torch.empty(max(nz, 1), dtype=torch.int32, device=dev),
-                            v=torch.empty(max(nz, 1), dtype=torch.float64, device=dev))
-            plan.export_csr_device(bufs["rp"].data_ptr(), bufs["ci"].data_ptr(), bufs["v"].data_ptr())
-            ctx.synchronize()
-            bufs["out"] = mg.gather_csr_slices(bufs["rp"], bufs["ci"][:nz], bufs["v"][:nz], dst=0)
+
+    def exchange():
+        """N>1 only: tiled C slice -> CSR on the device, then gather of the slices to rank 0 over RCCL"""
+        info = plan.info()
+        nrows, nz = info["row_end"] - info["row_begin"], info["nnz_c"]
+        if bufs.get("nz") != nz:
+            bufs.update(nz=nz, rp=torch.empty(nrows + 1, dtype=torch.int32, device=dev),
+                        ci=torch.empty(max(nz, 1), dtype=torch.int32, device=dev),
+                        v=torch.empty(max(nz, 1), dtype=torch.float64, device=dev))
+        plan.export_csr_device(bufs["rp"].data_ptr(), bufs["ci"].data_ptr(), bufs["v"].data_ptr())
+        ctx.synchronize()
+        bufs["out"] = mg.gather_csr_slices(bufs["rp"], bufs["ci"][:nz], bufs["v"][:nz], dst=0)
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(fn, n):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        fence()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            te = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            el = float(te.item())
+        return el
+
     for _ in range(args.warmup):
         step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+        if gather:
+            exchange()
+    elapsed = timed(step, args.steps)
+    # The metric times step1+2+3 (BASELINE.json); collecting the row blocks on one GPU is the path's exchange
+    # step and is timed separately over the same K passes (it is bounded by the root's xGMI ingest, not compute).
+    exchange_ms = timed(exchange, args.steps) * 1e3 / max(args.steps, 1) if gather else None
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     tm = ctx.timings()
     info = plan.info()
@@ -222,6 +234,10 @@ def main():
                                   "unit": "GB/s", "frac": b_alg / (t_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if t_kernel_ms > 0 else None,
                                   "note": "rank 0 slice: 12*(nnzA+nnzB+nnzC)+4*(rows+1)*3 over the hipEvent spans of step1+2+3"},
             "cpu_baseline": cpu_baseline,
+            "exchange": None if exchange_ms is None else {
+                "ms_per_step": exchange_ms, "what": "pem_c_export_csr_device + gather of the CSR row blocks to rank 0 (P2P over RCCL)",
+                "bytes_to_root": 12 * (total_nnz_c - info["nnz_c"]),
+                "value_with_exchange": 2.0 * flop / ((ms_per_step + exchange_ms) * 1e-3) / 1e9},
             "steps_ms": {"step1": tm["step1_ms"], "step2": tm["step2_ms"], "step3": tm["step3_ms"], "wall_last": tm["spgemm_wall_ms"]},
             "conversion_ms": {"A": A.conv_ms, "A_tile_kernels": A.conv_tile_kernel_ms},
             "kernels": kern,
