@@ -330,6 +330,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
             row.template expand_and_sort<4, LOGT>(tid);
         else if (EMAX == 8 || n <= THREADS * 8)
             row.template expand_and_sort<8, LOGT>(tid);
+        else if (n <= THREADS * 16)
+            row.template expand_and_sort<(EMAX > 8 ? 16 : 8), LOGT>(tid);
         else
             row.expand_and_sort_lds(tid);
         // stream out: sorted pairs, and per distinct tile column (C tile) its column + first pair
