@@ -103,7 +103,10 @@ pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const pem_tiled *B
 pem_status pem_cplan_destroy(pem_ctx *ctx, pem_cplan *plan);
 
 /* step 1 (spgemm.cu:1141-1218: tile_spgemm_step1_*_spa_kernel or the NSPARSE symbolic
- * path): tile-level symbolic product -> C tile list sorted by (tile row, tile col). */
+ * path): tile-level symbolic product -> C tile list sorted by (tile row, tile col).
+ * By default products whose A tile's occupied columns miss the B tile's occupied rows are
+ * dropped (they contribute nothing; the reference keeps them as empty pairs / empty C tiles).
+ * The final C is identical; PEM_PRUNE=0 in the environment reproduces the reference's lists. */
 pem_status pem_spgemm_step1(pem_ctx *ctx, pem_cplan *plan);
 /* step 2 (spgemm.cu:1220-1309: search_pairs<0/1>, compute_CMasksAndOffsets,
  * compute_CrowColIdx): pair lists, C tile bitmasks, per-tile nnz, intra-tile CSR. */
@@ -117,8 +120,9 @@ typedef struct {
     int32_t tile_row_begin, tile_row_end;
     int32_t row_begin, row_end;    /* matrix rows of C this plan produces */
     int64_t ntiles_c;              /* T_C  (_C_nnz, spgemm.cu:1169)        */
-    int64_t npairs;                /* P    (d_pairs_count, spgemm.cu:1246) */
+    int64_t npairs;                /* pairs kept: products whose tiles can meet (== npairs_all with PEM_PRUNE=0) */
     int64_t nnz_c;                 /* C_nnz (spgemm.cu:1291)               */
+    int64_t npairs_all;            /* P    (d_pairs_count, spgemm.cu:1246): every tile-level product, as the reference counts them */
 } pem_cplan_info;
 pem_status pem_cplan_get_info(const pem_cplan *plan, pem_cplan_info *info);
 

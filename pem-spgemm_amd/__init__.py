@@ -51,7 +51,7 @@ class TiledInfo(C.Structure):
 
 class CPlanInfo(C.Structure):
     _fields_ = [("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32),
-                ("ntiles_c", C.c_int64), ("npairs", C.c_int64), ("nnz_c", C.c_int64)]
+                ("ntiles_c", C.c_int64), ("npairs", C.c_int64), ("nnz_c", C.c_int64), ("npairs_all", C.c_int64)]
 
 
 class Timings(C.Structure):

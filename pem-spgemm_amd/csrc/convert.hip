@@ -94,7 +94,8 @@ __global__ void conv_fill_kernel(const uint64_t *__restrict__ keys, const uint32
 // ballot returns the four 16-bit transposed rows at once.
 __global__ void __launch_bounds__(256) conv_tile_meta_kernel(const uint8_t *__restrict__ rowcolidx, const int *__restrict__ tile_nnz_ptr,
                                                              long long ntiles, uint16_t *__restrict__ masks, uint8_t *__restrict__ rowptr,
-                                                             uint16_t *__restrict__ masks_t, uint32_t *__restrict__ rec)
+                                                             uint16_t *__restrict__ masks_t, uint32_t *__restrict__ rec,
+                                                             uint32_t *__restrict__ occ)
 {
     long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int r = threadIdx.x & 15;
@@ -122,6 +123,13 @@ __global__ void __launch_bounds__(256) conv_tile_meta_kernel(const uint8_t *__re
         unsigned mine = (unsigned)(ball >> (16 * grp)) & 0xFFFFu;
         if (r == m) bt = mine;
     }
+    // occupancy word: which columns hold an entry (OR of the row masks) | which rows are non-empty << 16
+    unsigned co = mask;
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) co |= (unsigned)__shfl_xor((int)co, d, 16);
+    const unsigned long long nzrows = __ballot(mask != 0);
+    const unsigned ro = (unsigned)(nzrows >> (16 * grp)) & 0xFFFFu;
+    if (live && r == 0) occ[t] = co | (ro << 16);
     if (live) {
         masks[16 * t + r] = (uint16_t)mask;
         rowptr[16 * t + r] = (uint8_t)(inc - cnt);
@@ -371,6 +379,7 @@ static pem_status build_tiled(pem_ctx *ctx, pem_tiled *T, DevBuf &k0, DevBuf &k1
     PEM_TRY(T->masks_t.reserve(sizeof(uint16_t) * 16 * (nt + 1)));
     PEM_TRY(T->rowptr.reserve(16 * (nt + 1)));
     PEM_TRY(T->tile_rec.reserve(sizeof(uint32_t) * 16 * (nt + 1)));
+    PEM_TRY(T->tile_occ.reserve(sizeof(uint32_t) * (nt + 4)));
     PEM_TRY(T->tile_rowptr.reserve(sizeof(int) * ((size_t)T->tile_rows + 4)));
     PEM_TRY(T->tile_colidx.reserve(sizeof(int) * (nt + 4)));
     PEM_TRY(T->tile_colptr.reserve(sizeof(int) * ((size_t)T->tile_cols + 4)));
@@ -384,7 +393,8 @@ static pem_status build_tiled(pem_ctx *ctx, pem_tiled *T, DevBuf &k0, DevBuf &k1
         PEM_LAUNCH(ctx, conv_fill_kernel, grid_for(nnz, 256), 256, keys, perm, head.as<int>(), nnz, dV, bits_tc, T->vals.as<double>(),
                    T->rowcolidx.as<uint8_t>(), T->tile_keys.as<long long>(), T->tile_nnz_ptr.as<int>());
         PEM_LAUNCH(ctx, conv_tile_meta_kernel, grid_for(nt * 16, 256), 256, T->rowcolidx.as<uint8_t>(), T->tile_nnz_ptr.as<int>(),
-                   (long long)ntiles, T->masks.as<uint16_t>(), T->rowptr.as<uint8_t>(), T->masks_t.as<uint16_t>(), T->tile_rec.as<uint32_t>());
+                   (long long)ntiles, T->masks.as<uint16_t>(), T->rowptr.as<uint8_t>(), T->masks_t.as<uint16_t>(), T->tile_rec.as<uint32_t>(),
+                   T->tile_occ.as<uint32_t>());
     }
     PEM_HIP(hipEventRecord(ctx->ev[7], st));
     if (nt) {

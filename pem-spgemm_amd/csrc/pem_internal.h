@@ -167,6 +167,7 @@ struct pem_tiled {
     pem::DevBuf tile_keys, tile_nnz_ptr, masks, rowptr, rowcolidx, vals, masks_t;
     pem::DevBuf tile_rowptr, tile_colidx, tile_colptr, tile_rowidx, tile_offsets;
     pem::DevBuf tile_rec;             // derived: uint32[16T] = masks[16t+r] | rowptr[16t+r] << 16 (one gather serves step 3)
+    pem::DevBuf tile_occ;             // derived: uint32[T] = occupied columns (low 16 bits) | occupied rows << 16 (step-1 pruning)
     std::vector<int> h_tile_rowptr;   // host copy (tile_rows+1 ints) for plan creation / splits
 };
 
@@ -181,6 +182,8 @@ struct pem_cplan {
     pem::DevBuf c_mask, c_tile_nnz_ptr, c_rowptr, c_rowcolidx, c_vals;
     // step-1 products kept for step 2 (expanded pair ids + the sorted permutation)
     pem::DevBuf prod_a, prod_b, aprod_off;
+    pem::DevBuf lprod_off;             // like aprod_off, counting only products whose tiles can meet (live products)
+    int64_t npairs_all = 0;            // all tile-level products (the reference's P) -- npairs counts the live ones
     pem::DevBuf sk0, sk1, sv0, sv1;    // sort buffers
     uint32_t *sorted_perm = nullptr;   // points into sv0/sv1
     // row-local step 1
@@ -189,7 +192,7 @@ struct pem_cplan {
     // sizes of the last complete pass on this plan.  A and B are immutable, so a repeat pass has the same
     // sizes: it skips the three host read-backs and a device-side check compares them at the end instead.
     bool warm = false, warm_pass = false;
-    int64_t w_P = 0, w_TC = 0, w_nnz = 0;
+    int64_t w_P = 0, w_Pall = 0, w_TC = 0, w_nnz = 0;
     int w_counts[4] = {0, 0, 0, 0};
     int64_t w_nxl = 0;
 };

@@ -23,37 +23,91 @@ using namespace pem;
 // ------------------------------------------------------------------------------------------
 // per A tile (i,k): number of tiles in B's tile row k (= tile-level intermediate products;
 // the quantity of spgemm_nsparse_kernel.h:135-151 per A tile instead of per row)
-__global__ void s1_aprod_kernel(const int *__restrict__ a_tile_colidx, int a_lo, int nA, const int *__restrict__ b_tile_rowptr,
-                                int *__restrict__ aprod)
+// A product (A tile (i,k), B tile (k,j)) can only contribute if some column occupied in the A tile is a row
+// occupied in the B tile.  The reference's tile-level symbolic product keeps every product and so
+// materialises pairs -- and whole C tiles -- that stay empty (83 % of the pairs of the scircuit stand-in).
+// With prune != 0 those dead products are dropped here, before anything is sorted or stored: the final C
+// is unchanged, only the intermediate C tile / pair lists lose their empty members.  prune == 0 reproduces
+// the reference's lists exactly.  16 lanes per A tile: aprod = all products, lprod = live products.
+__global__ void __launch_bounds__(256) s1_aprod_kernel(const int *__restrict__ a_tile_colidx, const uint32_t *__restrict__ a_occ, int a_lo,
+                                                       int nA, const int *__restrict__ b_tile_rowptr, const uint32_t *__restrict__ b_occ,
+                                                       int prune, int *__restrict__ aprod, int *__restrict__ lprod)
 {
-    int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= nA) return;
-    int k = a_tile_colidx[a_lo + a];
-    aprod[a] = b_tile_rowptr[k + 1] - b_tile_rowptr[k];
+    const int arel = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    const bool in = arel < nA;
+    int len = 0, cnt = 0;
+    if (in) {
+        const int k = a_tile_colidx[a_lo + arel];
+        const int b0 = b_tile_rowptr[k];
+        len = b_tile_rowptr[k + 1] - b0;
+        if (prune) {
+            const unsigned acol = a_occ[a_lo + arel] & 0xFFFFu;
+            for (int q = l; q < len; q += 16) cnt += (acol & (b_occ[b0 + q] >> 16)) != 0;
+        }
+    }
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 16);
+    if (in && l == 0) {
+        aprod[arel] = len;
+        lprod[arel] = prune ? cnt : len;
+    }
 }
 
-// expand: 16 lanes per A tile walk B's tile row k; product p gets key (i - tr_lo, j)
-__global__ void __launch_bounds__(256) s1_expand_kernel(const long long *__restrict__ a_tile_keys, int a_lo, int nA,
-                                                        const int *__restrict__ aprod_off, const int *__restrict__ b_tile_rowptr,
-                                                        const int *__restrict__ b_tile_colidx, int tr_lo, int bits_tc,
-                                                        uint64_t *__restrict__ keys, uint32_t *__restrict__ perm,
-                                                        int *__restrict__ prod_a, int *__restrict__ prod_b)
+// global expand (16 lanes per A tile walk B's tile row k): live products only, compacted by ballot;
+// product x gets key (i - tr_lo, j).  xl_base == nullptr: every row (PEM_STEP1=esc), positions = global
+// live offsets; else only the oversized rows (xl_base[i] >= 0), positions relative to the row's slot.
+__global__ void __launch_bounds__(256) s1_xl_expand_kernel(const long long *__restrict__ a_tile_keys, const int *__restrict__ a_tile_rowptr,
+                                                           const uint32_t *__restrict__ a_occ, int a_lo, int nA, int tr_lo,
+                                                           const int *__restrict__ lprod_off, const int *__restrict__ xl_base,
+                                                           const int *__restrict__ b_tile_rowptr, const int *__restrict__ b_tile_colidx,
+                                                           const uint32_t *__restrict__ b_occ, int prune, int bits_tc,
+                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, int *__restrict__ prod_a,
+                                                           int *__restrict__ prod_b)
 {
-    int arel = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    int l = threadIdx.x & 15;
-    if (arel >= nA) return;
-    int a = a_lo + arel;
-    long long ak = a_tile_keys[a];
-    int i = (int)(ak >> 32), k = (int)(ak & 0xFFFFFFFFll);
-    int b0 = b_tile_rowptr[k], len = b_tile_rowptr[k + 1] - b0;
-    int p0 = aprod_off[arel];
-    uint64_t hi = (uint64_t)(unsigned)(i - tr_lo) << bits_tc;
-    for (int q = l; q < len; q += 16) {
-        int p = p0 + q;
-        keys[p] = hi | (uint64_t)(unsigned)b_tile_colidx[b0 + q];
-        perm[p] = (uint32_t)p;
-        prod_a[p] = a;
-        prod_b[p] = b0 + q;
+    const int arel = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15, grp = (threadIdx.x & 63) >> 4;
+    const bool in = arel < nA;
+    int a = 0, i = 0, k = 0, x0 = -1, b0 = 0, len = 0;
+    unsigned acol = 0xFFFFu;
+    if (in) {
+        a = a_lo + arel;
+        const long long ak = a_tile_keys[a];
+        i = (int)(ak >> 32) - tr_lo;
+        k = (int)(ak & 0xFFFFFFFFll);
+        if (xl_base) {
+            const int base = xl_base[i];
+            if (base >= 0) x0 = base + (lprod_off[arel] - lprod_off[a_tile_rowptr[tr_lo + i] - a_lo]);
+        } else {
+            x0 = lprod_off[arel];
+        }
+        if (x0 >= 0) {
+            b0 = b_tile_rowptr[k];
+            len = b_tile_rowptr[k + 1] - b0;
+            if (prune) acol = a_occ[a] & 0xFFFFu;
+        }
+    }
+    // the four 16-lane groups of a wave walk different B rows: iterate to the longest, compact per group
+    int maxlen = len;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const int o = __shfl_xor(maxlen, d, 64);
+        maxlen = o > maxlen ? o : maxlen;
+    }
+    const uint64_t hi = (uint64_t)(unsigned)i << bits_tc;
+    int run = 0;
+    for (int q0 = 0; q0 < maxlen; q0 += 16) {
+        const int q = q0 + l;
+        const bool live = q < len && (!prune || (acol & (b_occ[b0 + q] >> 16)) != 0);
+        const unsigned m16 = (unsigned)(__ballot(live) >> (16 * grp)) & 0xFFFFu;
+        if (live) {
+            const int x = x0 + run + __popc(m16 & ((1u << l) - 1u));
+            keys[x] = hi | (uint64_t)(unsigned)b_tile_colidx[b0 + q];
+            perm[x] = (uint32_t)x;
+            prod_a[x] = a;
+            prod_b[x] = b0 + q;
+        }
+        run += __popc(m16);
     }
 }
 
@@ -107,20 +161,22 @@ __global__ void s1_c_rowptr_kernel(const int *__restrict__ c_rowidx, long long n
 constexpr int S1_CAP0 = 512, S1_CAP1 = 2048, S1_CAP2 = 8192, S1_CAP3 = 32768;
 
 __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int mt, int a_lo,
-                                                          const int *__restrict__ aprod_off, int cap3, int *__restrict__ row_list,
+                                                          const int *__restrict__ aprod_off, const int *__restrict__ lprod_off, int cap3,
+                                                          int *__restrict__ row_list,
                                                           int *__restrict__ bin_count, int *__restrict__ xl_base, int *__restrict__ row_tc)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    int n = 0;
+    int n = 0, nl = 0;
     if (i < mt) {
         int a0 = a_tile_rowptr[tr_lo + i] - a_lo, a1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
         n = aprod_off[a1] - aprod_off[a0];
+        nl = lprod_off[a1] - lprod_off[a0];
         xl_base[i] = -1;
         row_tc[i] = 0;
     }
-    const int bin = n == 0 ? -1 : n <= S1_CAP0 ? 0 : n <= S1_CAP1 ? 1 : n <= S1_CAP2 ? 2 : n <= cap3 ? 3 : 4;
+    const int bin = nl == 0 ? -1 : n <= S1_CAP0 ? 0 : n <= S1_CAP1 ? 1 : n <= S1_CAP2 ? 2 : n <= cap3 ? 3 : 4;
     // one atomic per wave and bin: ballot + prefix popcount hand out the slots (order is irrelevant)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -132,7 +188,7 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
         base = __shfl(base, leader, 64);
         if (bin == b) row_list[(size_t)b * mt + base + __popcll(m & lt)] = i;
     }
-    if (bin == 4) xl_base[i] = atomicAdd(&bin_count[5], n);   // oversized rows are few
+    if (bin == 4) xl_base[i] = atomicAdd(&bin_count[5], nl);   // oversized rows are few
 }
 
 // largest a in [lo, hi) with off[a] <= x
@@ -213,37 +269,43 @@ template <typename KeyT, int CAP, int QB, int THREADS, int RCAP>
 struct S1Row {
     KeyT *keys;
     const int *roff, *rbs;
+    const unsigned *rco;           // occupied columns of every A tile of the row (pruning)
     bool staged;
-    int R, a0, a1, p0, n, a_lo;
+    int R, a0, a1, p0, n, a_lo, prune;
     const int *a_tile_colidx, *aprod_off, *b_tile_rowptr, *b_tile_colidx;
-    __device__ __forceinline__ int tile_b(int q, int *a_out) const
+    const uint32_t *a_occ, *b_occ;
+    __device__ __forceinline__ int tile_b(int q, int *a_out, unsigned *acol_out = nullptr) const
     {
         int ar, b;
         if (staged) {
             ar = s1_find_a(roff, 0, R, q);
             b = rbs[ar] + (q - roff[ar]);
+            if (acol_out) *acol_out = rco[ar];
             ar += a0;
         } else {
             ar = s1_find_a(aprod_off, a0, a1, p0 + q);
             b = b_tile_rowptr[a_tile_colidx[a_lo + ar]] + (p0 + q - aprod_off[ar]);
+            if (acol_out) *acol_out = a_occ[a_lo + ar] & 0xFFFFu;
         }
         *a_out = a_lo + ar;
         return b;
+    }
+    // key of product q: (tile col, q); a product whose tiles cannot meet gets the padding key and sorts to the end
+    __device__ __forceinline__ KeyT product_key(int q) const
+    {
+        if (q >= n) return ~KeyT(0);
+        int a;
+        unsigned acol = 0xFFFFu;
+        const int b = tile_b(q, &a, prune ? &acol : nullptr);
+        if (prune && !(acol & (b_occ[b] >> 16))) return ~KeyT(0);
+        return (KeyT(b_tile_colidx[b]) << QB) | KeyT(q);
     }
     // more than 8 keys per thread: keep the keys in LDS (a register-resident sort of 16-32 keys per thread spills)
     __device__ __forceinline__ void expand_and_sort_lds(const int tid) const
     {
         int npad = 2;
         while (npad < n) npad <<= 1;
-        for (int q = tid; q < npad; q += THREADS) {
-            KeyT key = ~KeyT(0);
-            if (q < n) {
-                int a;
-                const int b = tile_b(q, &a);
-                key = (KeyT(b_tile_colidx[b]) << QB) | KeyT(q);
-            }
-            keys[q] = key;
-        }
+        for (int q = tid; q < npad; q += THREADS) keys[q] = product_key(q);
         __syncthreads();
         for (int kk = 2; kk <= npad; kk <<= 1) {
             for (int jj = kk >> 1; jj > 0; jj >>= 1) {
@@ -264,16 +326,7 @@ struct S1Row {
     {
         KeyT v[EPT];
 #pragma unroll
-        for (int m = 0; m < EPT; ++m) {
-            const int q = m * THREADS + tid;
-            KeyT key = ~KeyT(0);
-            if (q < n) {
-                int a;
-                const int b = tile_b(q, &a);
-                key = (KeyT(b_tile_colidx[b]) << QB) | KeyT(q);
-            }
-            v[m] = key;
-        }
+        for (int m = 0; m < EPT; ++m) v[m] = product_key(m * THREADS + tid);
         s1_bitonic_regs<KeyT, THREADS, EPT, LOGT>(v, keys, tid);
     }
 };
@@ -281,10 +334,12 @@ struct S1Row {
 template <typename KeyT, int CAP, int QB, int THREADS, int RCAP>
 __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8) : 1) s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr,
                                                              int tr_lo, int a_lo, const int *__restrict__ a_tile_colidx,
-                                                             const int *__restrict__ aprod_off, const int *__restrict__ b_tile_rowptr,
-                                                             const int *__restrict__ b_tile_colidx, int *__restrict__ pairs_a,
-                                                             int *__restrict__ pairs_b, int *__restrict__ scratch_col,
-                                                             int *__restrict__ scratch_off, int *__restrict__ row_tc)
+                                                             const int *__restrict__ aprod_off, const int *__restrict__ lprod_off,
+                                                             const int *__restrict__ b_tile_rowptr, const int *__restrict__ b_tile_colidx,
+                                                             const uint32_t *__restrict__ a_occ, const uint32_t *__restrict__ b_occ, int prune,
+                                                             int *__restrict__ pairs_a, int *__restrict__ pairs_b,
+                                                             int *__restrict__ scratch_col, int *__restrict__ scratch_off,
+                                                             int *__restrict__ row_tc)
 {
     constexpr int LOGT = THREADS == 64 ? 6 : THREADS == 256 ? 8 : 10;
     constexpr int EMAX = CAP / THREADS;
@@ -292,6 +347,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
     __shared__ KeyT keys[CAP];
     __shared__ int roff[RCAP + 1];     // product offset of every A tile of the row, relative to the row
     __shared__ int rbs[RCAP];          // first B tile id of that A tile's B tile row
+    __shared__ unsigned rco[RCAP];     // occupied columns of that A tile
     __shared__ int wsum[THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -301,6 +357,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
         row.keys = keys;
         row.roff = roff;
         row.rbs = rbs;
+        row.rco = rco;
+        row.prune = prune;
+        row.a_occ = a_occ;
+        row.b_occ = b_occ;
         row.a_lo = a_lo;
         row.a_tile_colidx = a_tile_colidx;
         row.aprod_off = aprod_off;
@@ -316,7 +376,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
         if (row.staged) {
             for (int x = tid; x <= row.R; x += THREADS) {
                 roff[x] = aprod_off[row.a0 + x] - p0;
-                if (x < row.R) rbs[x] = b_tile_rowptr[a_tile_colidx[a_lo + row.a0 + x]];
+                if (x < row.R) {
+                    rbs[x] = b_tile_rowptr[a_tile_colidx[a_lo + row.a0 + x]];
+                    rco[x] = a_occ[a_lo + row.a0 + x] & 0xFFFFu;
+                }
             }
         }
         __syncthreads();
@@ -334,11 +397,13 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
             row.template expand_and_sort<(EMAX > 8 ? 16 : 8), LOGT>(tid);
         else
             row.expand_and_sort_lds(tid);
-        // stream out: sorted pairs, and per distinct tile column (C tile) its column + first pair
+        // stream out the live products (the dead ones sorted behind them): sorted pairs, and per distinct tile
+        // column (C tile) its column + first pair; output positions count live products only
+        const int lp0 = lprod_off[row.a0], nlive = lprod_off[row.a1] - lp0;
         int base = 0;
-        for (int s0 = 0; s0 < n; s0 += THREADS) {
+        for (int s0 = 0; s0 < nlive; s0 += THREADS) {
             const int s = s0 + tid;
-            const bool valid = s < n;
+            const bool valid = s < nlive;
             int j = 0, a = 0, b = 0;
             bool head = false;
             if (valid) {
@@ -359,12 +424,12 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
                 tot += c;
             }
             if (valid) {
-                pairs_a[p0 + s] = a;
-                pairs_b[p0 + s] = b;
+                pairs_a[lp0 + s] = a;
+                pairs_b[lp0 + s] = b;
                 if (head) {
                     int rank = base + woff + __popcll(bal & lt);
-                    scratch_col[p0 + rank] = j;
-                    scratch_off[p0 + rank] = s;
+                    scratch_col[lp0 + rank] = j;
+                    scratch_off[lp0 + rank] = s;
                 }
             }
             base += tot;
@@ -374,34 +439,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
     }
 }
 
-// rows above S1_CAP2 products: global expand (16 lanes per A tile) + radix sort + emit
-__global__ void __launch_bounds__(256) s1_xl_expand_kernel(const long long *__restrict__ a_tile_keys, const int *__restrict__ a_tile_rowptr,
-                                                           int a_lo, int nA, int tr_lo, const int *__restrict__ aprod_off,
-                                                           const int *__restrict__ xl_base, const int *__restrict__ b_tile_rowptr,
-                                                           const int *__restrict__ b_tile_colidx, int bits_tc, uint64_t *__restrict__ keys,
-                                                           uint32_t *__restrict__ perm, int *__restrict__ prod_a, int *__restrict__ prod_b)
-{
-    int arel = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    int l = threadIdx.x & 15;
-    if (arel >= nA) return;
-    int a = a_lo + arel;
-    long long ak = a_tile_keys[a];
-    int i = (int)(ak >> 32) - tr_lo, k = (int)(ak & 0xFFFFFFFFll);
-    int base = xl_base[i];
-    if (base < 0) return;
-    int a0 = a_tile_rowptr[tr_lo + i] - a_lo;
-    int x0 = base + (aprod_off[arel] - aprod_off[a0]);
-    int b0 = b_tile_rowptr[k], len = b_tile_rowptr[k + 1] - b0;
-    uint64_t hi = (uint64_t)(unsigned)i << bits_tc;
-    for (int q = l; q < len; q += 16) {
-        int x = x0 + q;
-        keys[x] = hi | (uint64_t)(unsigned)b_tile_colidx[b0 + q];
-        perm[x] = (uint32_t)x;
-        prod_a[x] = a;
-        prod_b[x] = b0 + q;
-    }
-}
-
+// rows above the largest LDS bin: global expand (s1_xl_expand_kernel above) + radix sort + emit
 __global__ void s1_xl_rowstart_kernel(const uint64_t *__restrict__ keys, size_t n, int bits_tc, int *__restrict__ xl_rowstart)
 {
     size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -956,10 +994,10 @@ __global__ void split_rowprod_kernel(const int *__restrict__ a_tile_rowptr, cons
 
 
 // repeat pass on an unchanged plan: the sizes the host assumed (from the previous pass) against what this pass computed
-__global__ void warm_verify_kernel(const long long *__restrict__ d_scalars, const int *__restrict__ bin_count, long long P, long long TC,
+__global__ void warm_verify_kernel(const long long *__restrict__ d_scalars, const int *__restrict__ bin_count, long long P, long long Pall, long long TC,
                                    long long nnz, int c0, int c1, int c2, int c3, long long nxl, int *__restrict__ flags)
 {
-    if (d_scalars[0] != P || d_scalars[1] != TC || d_scalars[2] != nnz || bin_count[0] != c0 || bin_count[1] != c1 || bin_count[2] != c2 ||
+    if (d_scalars[0] != P || d_scalars[1] != TC || d_scalars[2] != nnz || d_scalars[3] != Pall || bin_count[0] != c0 || bin_count[1] != c1 || bin_count[2] != c2 ||
         bin_count[3] != c3 || bin_count[5] != nxl)
         flags[FLAG_CAPACITY] = 1;
 }
@@ -1011,6 +1049,7 @@ extern "C" pem_status pem_cplan_get_info(const pem_cplan *p, pem_cplan_info *inf
     info->ntiles_c = p->ntiles_c;
     info->npairs = p->npairs;
     info->nnz_c = p->nnz_c;
+    info->npairs_all = p->npairs_all;
     return PEM_OK;
 }
 
@@ -1033,16 +1072,27 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
     p->ntiles_c = p->npairs = p->nnz_c = 0;
     PEM_TRY(zero_flags(ctx));
     PEM_HIP(hipEventRecord(ctx->ev[0], st));
-    PEM_TRY(p->aprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
     PEM_TRY(p->c_tile_rowptr.reserve(sizeof(int) * ((size_t)mt + 4)));
     PEM_HIP(hipMemsetAsync(p->c_tile_rowptr.p, 0, sizeof(int) * ((size_t)mt + 1), st));
+    // product offsets per A tile: all products (expansion / sort capacity) and live products (output positions)
+    const char *prune_env = getenv("PEM_PRUNE");
+    const int prune = !(prune_env && !strcmp(prune_env, "0"));
+    PEM_TRY(p->aprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
+    PEM_TRY(p->lprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
     if (nA > 0)
-        PEM_LAUNCH(ctx, s1_aprod_kernel, grid_for((size_t)nA, 256), 256, A->tile_colidx.as<int>(), p->a_lo, nA, B->tile_rowptr.as<int>(),
-                   p->aprod_off.as<int>());
-    PEM_TRY(exclusive_scan_i32(ctx, p->aprod_off.as<int>(), p->aprod_off.as<int>(), (size_t)nA, ctx->d_scalars));
-    int64_t P = 0;
-    PEM_TRY(read_scalars(ctx, ctx->d_scalars, 1, &P));
-    if (P > 0x7FFFFFFFll) {
+        PEM_LAUNCH(ctx, s1_aprod_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_colidx.as<int>(), A->tile_occ.as<uint32_t>(), p->a_lo, nA,
+                   B->tile_rowptr.as<int>(), B->tile_occ.as<uint32_t>(), prune, p->aprod_off.as<int>(), p->lprod_off.as<int>());
+    PEM_TRY(exclusive_scan_i32(ctx, p->aprod_off.as<int>(), p->aprod_off.as<int>(), (size_t)nA, ctx->d_scalars + 3));
+    PEM_TRY(exclusive_scan_i32(ctx, p->lprod_off.as<int>(), p->lprod_off.as<int>(), (size_t)nA, ctx->d_scalars));
+    int64_t P = 0, Pall = 0;
+    {
+        int64_t two[4];
+        PEM_TRY(read_scalars(ctx, ctx->d_scalars, 4, two));
+        P = two[0];
+        Pall = two[3];
+    }
+    p->npairs_all = Pall;
+    if (P > 0x7FFFFFFFll || Pall > 0x7FFFFFFFll) {
         set_error("step 1: %lld tile pairs exceed the int32 range of the reference's pair arrays", (long long)P);
         return PEM_E_OVERFLOW;
     }
@@ -1057,8 +1107,9 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->sk1.reserve(sizeof(uint64_t) * n));
         PEM_TRY(p->sv0.reserve(sizeof(uint32_t) * n));
         PEM_TRY(p->sv1.reserve(sizeof(uint32_t) * n));
-        PEM_LAUNCH(ctx, s1_expand_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_keys.as<long long>(), p->a_lo, nA, p->aprod_off.as<int>(),
-                   B->tile_rowptr.as<int>(), B->tile_colidx.as<int>(), p->tr_lo, bits_tc, p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(),
+        PEM_LAUNCH(ctx, s1_xl_expand_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_keys.as<long long>(), A->tile_rowptr.as<int>(),
+                   A->tile_occ.as<uint32_t>(), p->a_lo, nA, p->tr_lo, p->lprod_off.as<int>(), (const int *)nullptr, B->tile_rowptr.as<int>(),
+                   B->tile_colidx.as<int>(), B->tile_occ.as<uint32_t>(), prune, bits_tc, p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(),
                    p->prod_a.as<int>(), p->prod_b.as<int>());
         uint64_t *keys = nullptr;
         PEM_TRY(radix_sort_u64_u32(ctx, p->sk0.as<uint64_t>(), p->sk1.as<uint64_t>(), p->sv0.as<uint32_t>(), p->sv1.as<uint32_t>(), n,
@@ -1086,7 +1137,7 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
 }
 
 template <typename KeyT>
-static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int mt, int cap3)
+static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int mt, int cap3, int prune)
 {
     const pem_tiled *A = p->A, *B = p->B;
     int *rl = p->row_list.as<int>();
@@ -1095,8 +1146,9 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
         int grid = counts[BIN] < (MAXGRID) ? counts[BIN] : (MAXGRID);                                                                \
         PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<" #CAP ">", (s1_rowsort_kernel<KeyT, CAP, QB, THREADS, RCAP>), grid, THREADS,             \
                          rl + (size_t)(BIN) * mt, counts[BIN], A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, A->tile_colidx.as<int>(), \
-                         p->aprod_off.as<int>(), B->tile_rowptr.as<int>(), B->tile_colidx.as<int>(), p->pairs_a.as<int>(),             \
-                         p->pairs_b.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->c_tile_rowptr.as<int>());       \
+                         p->aprod_off.as<int>(), p->lprod_off.as<int>(), B->tile_rowptr.as<int>(), B->tile_colidx.as<int>(),         \
+                         A->tile_occ.as<uint32_t>(), B->tile_occ.as<uint32_t>(), prune, p->pairs_a.as<int>(), p->pairs_b.as<int>(),   \
+                         p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->c_tile_rowptr.as<int>());                             \
     }
     // The largest bin is a handful of rows, one 1024-thread block per CU, each running long: fork it onto the
     // auxiliary stream so the other bins fill the rest of the chip meanwhile; joined before the row-count scan.
@@ -1133,42 +1185,54 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     p->ntiles_c = p->npairs = p->nnz_c = 0;
     PEM_TRY(zero_flags(ctx));
     PEM_HIP(hipEventRecord(ctx->ev[0], st));
-    PEM_TRY(p->aprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
     PEM_TRY(p->c_tile_rowptr.reserve(sizeof(int) * ((size_t)mt + 4)));
     PEM_TRY(p->row_list.reserve(sizeof(int) * (5 * (size_t)mt + 4)));
     PEM_TRY(p->bin_count.reserve(sizeof(int) * 8));
     PEM_TRY(p->xl_base.reserve(sizeof(int) * ((size_t)mt + 4)));
     PEM_TRY(p->pairs_offset.reserve(sizeof(int) * 4));
     PEM_HIP(hipMemsetAsync(p->bin_count.p, 0, sizeof(int) * 8, st));
-    PEM_HIP(hipMemsetAsync(ctx->d_scalars, 0, sizeof(int64_t) * 3, st));   // P, T_C, C_nnz of this pass
+    PEM_HIP(hipMemsetAsync(ctx->d_scalars, 0, sizeof(int64_t) * 4, st));   // P (live), T_C, C_nnz, P (all) of this pass
     PEM_HIP(hipMemsetAsync(p->c_tile_rowptr.p, 0, sizeof(int) * ((size_t)mt + 1), st));
     PEM_HIP(hipMemsetAsync(p->pairs_offset.p, 0, sizeof(int), st));
+    // product offsets per A tile: all products (expansion / sort capacity) and live products (output positions)
+    const char *prune_env = getenv("PEM_PRUNE");
+    const int prune = !(prune_env && !strcmp(prune_env, "0"));
+    PEM_TRY(p->aprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
+    PEM_TRY(p->lprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
     if (nA > 0)
-        PEM_LAUNCH(ctx, s1_aprod_kernel, grid_for((size_t)nA, 256), 256, A->tile_colidx.as<int>(), p->a_lo, nA, B->tile_rowptr.as<int>(),
-                   p->aprod_off.as<int>());
-    PEM_TRY(exclusive_scan_i32(ctx, p->aprod_off.as<int>(), p->aprod_off.as<int>(), (size_t)nA, ctx->d_scalars));
+        PEM_LAUNCH(ctx, s1_aprod_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_colidx.as<int>(), A->tile_occ.as<uint32_t>(), p->a_lo, nA,
+                   B->tile_rowptr.as<int>(), B->tile_occ.as<uint32_t>(), prune, p->aprod_off.as<int>(), p->lprod_off.as<int>());
+    PEM_TRY(exclusive_scan_i32(ctx, p->aprod_off.as<int>(), p->aprod_off.as<int>(), (size_t)nA, ctx->d_scalars + 3));
+    PEM_TRY(exclusive_scan_i32(ctx, p->lprod_off.as<int>(), p->lprod_off.as<int>(), (size_t)nA, ctx->d_scalars));
     // per-row tile counts are accumulated in c_tile_rowptr and scanned in place afterwards
     if (mt > 0)
         PEM_LAUNCH(ctx, s1_rowclass_kernel, grid_for((size_t)mt, 256), 256, A->tile_rowptr.as<int>(), p->tr_lo, mt, p->a_lo,
-                   p->aprod_off.as<int>(), cap3, p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(), p->c_tile_rowptr.as<int>());
+                   p->aprod_off.as<int>(), p->lprod_off.as<int>(), cap3, p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(),
+                   p->c_tile_rowptr.as<int>());
     // one read-back: P, the bin populations and the product total of the oversized rows
-    int64_t P = 0;
+    int64_t P = 0, Pall = 0;
     int counts[4];
     size_t n_xl;
     if (p->warm_pass) {
         P = p->w_P;
+        Pall = p->w_Pall;
         for (int b = 0; b < 4; ++b) counts[b] = p->w_counts[b];
         n_xl = (size_t)p->w_nxl;
     } else {
         int *hb = reinterpret_cast<int *>(ctx->h_scalars + 32);
         PEM_HIP(hipMemcpyAsync(hb, p->bin_count.p, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
-        PEM_TRY(read_scalars(ctx, ctx->d_scalars, 1, &P));
+        int64_t sc[4];
+        PEM_TRY(read_scalars(ctx, ctx->d_scalars, 4, sc));
+        P = sc[0];
+        Pall = sc[3];
         for (int b = 0; b < 4; ++b) counts[b] = p->w_counts[b] = hb[b];
         n_xl = (size_t)hb[5];
         p->w_nxl = (int64_t)n_xl;
         p->w_P = P;
+        p->w_Pall = Pall;
     }
-    if (P > 0x7FFFFFFFll) {
+    p->npairs_all = Pall;
+    if (P > 0x7FFFFFFFll || Pall > 0x7FFFFFFFll) {
         set_error("step 1: %lld tile pairs exceed the int32 range of the reference's pair arrays", (long long)P);
         return PEM_E_OVERFLOW;
     }
@@ -1181,9 +1245,9 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->scratch_col.reserve(sizeof(int) * (n + 4)));
         PEM_TRY(p->scratch_off.reserve(sizeof(int) * (n + 4)));
         if (bits_tc + 13 <= 32)
-            launch_rowsorts<uint32_t>(ctx, p, counts, mt, cap3);
+            launch_rowsorts<uint32_t>(ctx, p, counts, mt, cap3, prune);
         else
-            launch_rowsorts<uint64_t>(ctx, p, counts, mt, cap3);
+            launch_rowsorts<uint64_t>(ctx, p, counts, mt, cap3, prune);
         if (n_xl > 0) {   // oversized rows: global expand + stable radix sort on (row, tile col)
             PEM_TRY(p->prod_a.reserve(sizeof(int) * n_xl));
             PEM_TRY(p->prod_b.reserve(sizeof(int) * n_xl));
@@ -1193,8 +1257,9 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
             PEM_TRY(p->sv1.reserve(sizeof(uint32_t) * n_xl));
             PEM_TRY(p->xl_rowstart.reserve(sizeof(int) * ((size_t)mt + 4)));
             PEM_LAUNCH(ctx, s1_xl_expand_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_keys.as<long long>(), A->tile_rowptr.as<int>(),
-                       p->a_lo, nA, p->tr_lo, p->aprod_off.as<int>(), p->xl_base.as<int>(), B->tile_rowptr.as<int>(), B->tile_colidx.as<int>(),
-                       bits_tc, p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(), p->prod_a.as<int>(), p->prod_b.as<int>());
+                       A->tile_occ.as<uint32_t>(), p->a_lo, nA, p->tr_lo, p->lprod_off.as<int>(), p->xl_base.as<int>(), B->tile_rowptr.as<int>(),
+                       B->tile_colidx.as<int>(), B->tile_occ.as<uint32_t>(), prune, bits_tc, p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(),
+                       p->prod_a.as<int>(), p->prod_b.as<int>());
             uint64_t *keys = nullptr;
             uint32_t *perm = nullptr;
             PEM_TRY(radix_sort_u64_u32(ctx, p->sk0.as<uint64_t>(), p->sk1.as<uint64_t>(), p->sv0.as<uint32_t>(), p->sv1.as<uint32_t>(), n_xl,
@@ -1205,7 +1270,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
             PEM_TRY(exclusive_scan_i32(ctx, head.as<int>(), head.as<int>(), n_xl, nullptr));
             PEM_LAUNCH(ctx, s1_xl_rowstart_kernel, grid_for(n_xl, 256), 256, keys, n_xl, bits_tc, p->xl_rowstart.as<int>());
             PEM_LAUNCH(ctx, s1_xl_emit_kernel, grid_for(n_xl, 256), 256, keys, perm, head.as<int>(), n_xl, bits_tc, p->xl_rowstart.as<int>(),
-                       A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->aprod_off.as<int>(), p->prod_a.as<int>(), p->prod_b.as<int>(),
+                       A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->lprod_off.as<int>(), p->prod_a.as<int>(), p->prod_b.as<int>(),
                        p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(),
                        p->c_tile_rowptr.as<int>());
         }
@@ -1222,7 +1287,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
         PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
         PEM_LAUNCH(ctx, s1_compact_kernel, grid_for((size_t)mt * 64, 256), 256, p->c_tile_rowptr.as<int>(), mt, (long long)TC, p->tr_lo,
-                   A->tile_rowptr.as<int>(), p->a_lo, p->aprod_off.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), (int)P,
+                   A->tile_rowptr.as<int>(), p->a_lo, p->lprod_off.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), (int)P,
                    p->c_tile_rowidx.as<int>(), p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>());
         p->pairs_ready = true;
     }
@@ -1370,7 +1435,7 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
     if (plan->warm_pass) {
         // repeat pass: the host never waited for P / T_C / C_nnz; check on the device that they are what it assumed
         PEM_LAUNCH(ctx, warm_verify_kernel, 1, 1, reinterpret_cast<const long long *>(ctx->d_scalars), plan->bin_count.as<int>(),
-                   (long long)plan->w_P, (long long)plan->w_TC, (long long)plan->w_nnz, plan->w_counts[0], plan->w_counts[1], plan->w_counts[2],
+                   (long long)plan->w_P, (long long)plan->w_Pall, (long long)plan->w_TC, (long long)plan->w_nnz, plan->w_counts[0], plan->w_counts[1], plan->w_counts[2],
                    plan->w_counts[3], (long long)plan->w_nxl, ctx->d_flags);
         int hf[NUM_FLAGS];
         PEM_TRY(read_flags(ctx, hf));   // the pass's one synchronisation

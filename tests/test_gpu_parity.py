@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 from matgen import cases
+from prune_ref import expected
 
 pytestmark = pytest.mark.gpu
 
@@ -41,9 +42,10 @@ def test_three_steps_match_oracle(pkg, oracle, ctx, name):
     plan.step3()
     op = oracle.Plan(oA, oB)
     info = plan.info()
-    assert (info["ntiles_c"], info["npairs"], info["nnz_c"]) == (op.ntiles_c, op.npairs, op.nnz_c)
+    want_arrays, want_counts = expected(op, oA, oB)      # the oracle's arrays minus dead pairs / empty tiles
+    assert (info["ntiles_c"], info["npairs"], info["nnz_c"], info["npairs_all"]) == want_counts
     for arr in C_NAMES:
-        got, want = plan.array(arr), getattr(op, arr)
+        got, want = plan.array(arr), want_arrays[arr]
         assert got.dtype == want.dtype and np.array_equal(got, want), f"{name}: plan array {arr} differs"
     assert pkg.flop_count(ctx, gA, gB) == oracle.flop_count(oA, oB)
     # a14: CSR / sorted COO, against the tiled oracle and the independent serial CSR Gustavson
@@ -81,9 +83,9 @@ def test_global_sort_step1_matches_row_local_step1(pkg, oracle, ctx, name, monke
     gA, gB, oA, oB = _tiled_pair(pkg, oracle, ctx, CASES[name])
     plan = pkg.CPlan(ctx, gA, gB)
     plan.spgemm()
-    op = oracle.Plan(oA, oB)
+    want_arrays, _ = expected(oracle.Plan(oA, oB), oA, oB)
     for arr in C_NAMES:
-        assert np.array_equal(plan.array(arr), getattr(op, arr)), f"{name}: plan array {arr} differs (esc)"
+        assert np.array_equal(plan.array(arr), want_arrays[arr]), f"{name}: plan array {arr} differs (esc)"
 
 
 @pytest.mark.parametrize("name", ["powerlaw_600", "dense_48", "rect_70x40_AAt", "hub_row_4000", "empty_matrix"])
@@ -93,9 +95,9 @@ def test_narrow_step23_kernels_match(pkg, oracle, ctx, name, monkeypatch):
     gA, gB, oA, oB = _tiled_pair(pkg, oracle, ctx, CASES[name])
     plan = pkg.CPlan(ctx, gA, gB)
     plan.spgemm()
-    op = oracle.Plan(oA, oB)
+    want_arrays, _ = expected(oracle.Plan(oA, oB), oA, oB)
     for arr in C_NAMES:
-        assert np.array_equal(plan.array(arr), getattr(op, arr)), f"{name}: plan array {arr} differs (narrow)"
+        assert np.array_equal(plan.array(arr), want_arrays[arr]), f"{name}: plan array {arr} differs (narrow)"
 
 
 def test_repeat_passes_skip_readbacks_and_stay_identical(pkg, oracle, ctx, monkeypatch):
@@ -114,9 +116,9 @@ def test_repeat_passes_skip_readbacks_and_stay_identical(pkg, oracle, ctx, monke
         plan.spgemm()
         forced = [plan.array(a) for a in C_NAMES]
         monkeypatch.delenv("PEM_NO_WARM")
-        op = oracle.Plan(oA, oB)
+        want_arrays, _ = expected(oracle.Plan(oA, oB), oA, oB)
         for a, c, w, f in zip(C_NAMES, cold, warm, forced):
-            want = getattr(op, a)
+            want = want_arrays[a]
             assert np.array_equal(c, want) and np.array_equal(w, want) and np.array_equal(f, want), (name, a)
 
 
@@ -132,3 +134,20 @@ def test_row_serial_export_matches(pkg, oracle, ctx, name, monkeypatch):
     want = oracle.Plan(oA, oB).export_csr()
     for a, b, c in zip(fast, slow, want):
         assert np.array_equal(a, c) and np.array_equal(b, c)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_unpruned_lists_are_the_reference_lists(pkg, oracle, ctx, name, monkeypatch):
+    """PEM_PRUNE=0: every tile-level product is kept, so C tile list, pair lists and every count equal the
+    reference-faithful oracle's exactly -- for the row-local and for the global step 1."""
+    monkeypatch.setenv("PEM_PRUNE", "0")
+    gA, gB, oA, oB = _tiled_pair(pkg, oracle, ctx, CASES[name])
+    op = oracle.Plan(oA, oB)
+    for mode in ("rows", "esc"):
+        monkeypatch.setenv("PEM_STEP1", mode)
+        plan = pkg.CPlan(ctx, gA, gB)
+        plan.spgemm()
+        info = plan.info()
+        assert (info["ntiles_c"], info["npairs"], info["nnz_c"], info["npairs_all"]) == (op.ntiles_c, op.npairs, op.nnz_c, op.npairs)
+        for arr in C_NAMES:
+            assert np.array_equal(plan.array(arr), getattr(op, arr)), f"{name}/{mode}: plan array {arr} differs (unpruned)"
