@@ -162,7 +162,7 @@ constexpr int S1_CAP0 = 512, S1_CAP1 = 2048, S1_CAP2 = 8192, S1_CAP3 = 32768;
 
 __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int mt, int a_lo,
                                                           const int *__restrict__ aprod_off, const int *__restrict__ lprod_off, int cap3,
-                                                          int *__restrict__ row_list,
+                                                          int qcap, int *__restrict__ row_list,
                                                           int *__restrict__ bin_count, int *__restrict__ xl_base, int *__restrict__ row_tc)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -176,7 +176,8 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
         xl_base[i] = -1;
         row_tc[i] = 0;
     }
-    const int bin = nl == 0 ? -1 : n <= S1_CAP0 ? 0 : n <= S1_CAP1 ? 1 : n <= S1_CAP2 ? 2 : n <= cap3 ? 3 : 4;
+    // bins by LIVE products (what gets sorted); the key's index field must still hold every product of the row
+    const int bin = nl == 0 ? -1 : n > qcap ? 4 : nl <= S1_CAP0 ? 0 : nl <= S1_CAP1 ? 1 : nl <= S1_CAP2 ? 2 : nl <= cap3 ? 3 : 4;
     // one atomic per wave and bin: ballot + prefix popcount hand out the slots (order is irrelevant)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -300,12 +301,40 @@ struct S1Row {
         if (prune && !(acol & (b_occ[b] >> 16))) return ~KeyT(0);
         return (KeyT(b_tile_colidx[b]) << QB) | KeyT(q);
     }
-    // more than 8 keys per thread: keep the keys in LDS (a register-resident sort of 16-32 keys per thread spills)
-    __device__ __forceinline__ void expand_and_sort_lds(const int tid) const
+    // expand all n products of the row, keep the live ones: their keys are packed into keys[0..nlive) in
+    // arbitrary order (ballot + one LDS atomic per wave and chunk) -- the sort that follows fixes the order,
+    // and only live keys get sorted.  Returns nlive; keys[nlive..npad_to) are set to the padding key.
+    __device__ __forceinline__ int expand_compact(const int tid, int *s_cnt, int npad_to_mult) const
+    {
+        const int lane = tid & 63;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        for (int q0 = 0; q0 < n; q0 += THREADS) {
+            const KeyT key = product_key(q0 + tid);
+            const bool live = key != ~KeyT(0);
+            const unsigned long long bal = __ballot(live);
+            if (bal) {
+                int base = 0;
+                const int leader = __builtin_ctzll(bal);
+                if (lane == leader) base = atomicAdd(s_cnt, __popcll(bal));
+                base = __shfl(base, leader, 64);
+                if (live) keys[base + __popcll(bal & lt)] = key;
+            }
+        }
+        __syncthreads();
+        const int nlive = *s_cnt;
+        int upto = npad_to_mult;               // THREADS * 2^e >= nlive: what the register sort will load
+        while (upto < nlive) upto <<= 1;
+        if (upto > CAP) upto = CAP;
+        for (int x = nlive + tid; x < upto; x += THREADS) keys[x] = ~KeyT(0);
+        __syncthreads();
+        return nlive;
+    }
+    // more than 16 keys per thread: sort in LDS (a register-resident sort of 32 keys per thread spills)
+    __device__ __forceinline__ void sort_lds(const int tid, const int nlive) const
     {
         int npad = 2;
-        while (npad < n) npad <<= 1;
-        for (int q = tid; q < npad; q += THREADS) keys[q] = product_key(q);
+        while (npad < nlive) npad <<= 1;
+        for (int x = nlive + tid; x < npad; x += THREADS) keys[x] = ~KeyT(0);
         __syncthreads();
         for (int kk = 2; kk <= npad; kk <<= 1) {
             for (int jj = kk >> 1; jj > 0; jj >>= 1) {
@@ -322,11 +351,12 @@ struct S1Row {
             }
         }
     }
-    template <int EPT, int LOGT> __device__ __forceinline__ void expand_and_sort(const int tid) const
+    template <int EPT, int LOGT> __device__ __forceinline__ void sort_regs(const int tid) const
     {
         KeyT v[EPT];
 #pragma unroll
-        for (int m = 0; m < EPT; ++m) v[m] = product_key(m * THREADS + tid);
+        for (int m = 0; m < EPT; ++m) v[m] = keys[m * THREADS + tid];
+        __syncthreads();   // everyone has its keys in registers before the sort's LDS stages overwrite them
         s1_bitonic_regs<KeyT, THREADS, EPT, LOGT>(v, keys, tid);
     }
 };
@@ -349,10 +379,12 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
     __shared__ int rbs[RCAP];          // first B tile id of that A tile's B tile row
     __shared__ unsigned rco[RCAP];     // occupied columns of that A tile
     __shared__ int wsum[THREADS / 64];
+    __shared__ int s_cnt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int li = blockIdx.x; li < nrows_bin; li += gridDim.x) {
         const int i = row_list[li];
+        if (tid == 0) s_cnt = 0;
         S1Row<KeyT, CAP, QB, THREADS, RCAP> row;
         row.keys = keys;
         row.roff = roff;
@@ -383,23 +415,24 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
             }
         }
         __syncthreads();
-        // expand the row's products into (tile col, product index) keys and sort them; equal tile
-        // columns stay in product (= ascending k) order because the index is part of the key
-        if (n <= THREADS)
-            row.template expand_and_sort<1, LOGT>(tid);
-        else if (n <= THREADS * 2)
-            row.template expand_and_sort<2, LOGT>(tid);
-        else if (n <= THREADS * 4)
-            row.template expand_and_sort<4, LOGT>(tid);
-        else if (EMAX == 8 || n <= THREADS * 8)
-            row.template expand_and_sort<8, LOGT>(tid);
-        else if (n <= THREADS * 16)
-            row.template expand_and_sort<(EMAX > 8 ? 16 : 8), LOGT>(tid);
+        // expand the row's products into (tile col, product index) keys -- live ones only -- and sort them; equal
+        // tile columns stay in product (= ascending k) order because the index is part of the key
+        const int nl = row.expand_compact(tid, &s_cnt, THREADS);
+        if (nl <= THREADS)
+            row.template sort_regs<1, LOGT>(tid);
+        else if (nl <= THREADS * 2)
+            row.template sort_regs<2, LOGT>(tid);
+        else if (nl <= THREADS * 4)
+            row.template sort_regs<4, LOGT>(tid);
+        else if (nl <= THREADS * 8)
+            row.template sort_regs<8, LOGT>(tid);
+        else if (EMAX > 8 && nl <= THREADS * 16)
+            row.template sort_regs<(EMAX > 8 ? 16 : 8), LOGT>(tid);
         else
-            row.expand_and_sort_lds(tid);
+            row.sort_lds(tid, nl);
         // stream out the live products (the dead ones sorted behind them): sorted pairs, and per distinct tile
         // column (C tile) its column + first pair; output positions count live products only
-        const int lp0 = lprod_off[row.a0], nlive = lprod_off[row.a1] - lp0;
+        const int lp0 = lprod_off[row.a0], nlive = nl;
         int base = 0;
         for (int s0 = 0; s0 < nlive; s0 += THREADS) {
             const int s = s0 + tid;
@@ -408,7 +441,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
             bool head = false;
             if (valid) {
                 KeyT key = keys[s];
-                int q = (int)(key & KeyT(CAP - 1));
+                int q = (int)(key & KeyT((1u << QB) - 1u));
                 j = (int)(key >> QB);
                 head = s == 0 || (int)(keys[s - 1] >> QB) != j;
                 b = row.tile_b(q, &a);
@@ -1141,6 +1174,7 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
 {
     const pem_tiled *A = p->A, *B = p->B;
     int *rl = p->row_list.as<int>();
+    constexpr int QBITS = sizeof(KeyT) == 4 ? 15 : 24;   // product-index field of the sort key
 #define PEM_ROWSORT(BIN, CAP, QB, THREADS, RCAP, MAXGRID)                                                                                 \
     if (counts[BIN] > 0) {                                                                                                           \
         int grid = counts[BIN] < (MAXGRID) ? counts[BIN] : (MAXGRID);                                                                \
@@ -1159,15 +1193,15 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
             (void)hipEventRecord(ctx->ev_fork, main_stream);
             (void)hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0);
             ctx->stream = ctx->aux;
-            PEM_ROWSORT(3, 32768, 15, 1024, 2048, 1 << 20)
+            PEM_ROWSORT(3, 32768, QBITS, 1024, 2048, 1 << 20)
             (void)hipEventRecord(ctx->ev_join, ctx->aux);
             ctx->stream = main_stream;
             forked = true;
         }
     }
-    PEM_ROWSORT(2, 8192, 13, 1024, 2048, 1 << 20)
-    PEM_ROWSORT(1, 2048, 11, 256, 1024, 1 << 20)
-    PEM_ROWSORT(0, 512, 9, 64, 256, 1 << 20)
+    PEM_ROWSORT(2, 8192, QBITS, 1024, 2048, 1 << 20)
+    PEM_ROWSORT(1, 2048, QBITS, 256, 1024, 1 << 20)
+    PEM_ROWSORT(0, 512, QBITS, 64, 256, 1 << 20)
 #undef PEM_ROWSORT
     if (forked) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
 }
@@ -1179,7 +1213,10 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     const int nA = p->a_hi - p->a_lo, mt = p->tr_hi - p->tr_lo;
     const int bits_tc = bits_for((uint64_t)B->tile_cols), bits_row = bits_for((uint64_t)(mt > 0 ? mt : 1));
     // the 32768-key LDS bin needs 32-bit keys (tile col + 15 index bits); wider B goes to the global path above 8192
-    const int cap3 = bits_tc + 15 <= 32 ? S1_CAP3 : S1_CAP2;
+    // 32-bit keys = tile col + 15 index bits; wider B uses 64-bit keys (24 index bits, no 32768-key LDS bin)
+    const bool k32 = bits_tc + 15 <= 32;
+    const int cap3 = k32 ? S1_CAP3 : S1_CAP2;
+    const int qcap = k32 ? (1 << 15) : (1 << 24);
     p->state = 0;
     p->pairs_ready = false;
     p->ntiles_c = p->npairs = p->nnz_c = 0;
@@ -1207,7 +1244,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     // per-row tile counts are accumulated in c_tile_rowptr and scanned in place afterwards
     if (mt > 0)
         PEM_LAUNCH(ctx, s1_rowclass_kernel, grid_for((size_t)mt, 256), 256, A->tile_rowptr.as<int>(), p->tr_lo, mt, p->a_lo,
-                   p->aprod_off.as<int>(), p->lprod_off.as<int>(), cap3, p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(),
+                   p->aprod_off.as<int>(), p->lprod_off.as<int>(), cap3, qcap, p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(),
                    p->c_tile_rowptr.as<int>());
     // one read-back: P, the bin populations and the product total of the oversized rows
     int64_t P = 0, Pall = 0;
@@ -1244,7 +1281,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->pairs_b.reserve(sizeof(int) * (n + 4)));
         PEM_TRY(p->scratch_col.reserve(sizeof(int) * (n + 4)));
         PEM_TRY(p->scratch_off.reserve(sizeof(int) * (n + 4)));
-        if (bits_tc + 13 <= 32)
+        if (k32)
             launch_rowsorts<uint32_t>(ctx, p, counts, mt, cap3, prune);
         else
             launch_rowsorts<uint64_t>(ctx, p, counts, mt, cap3, prune);
