@@ -28,6 +28,11 @@ const char *pem_host_last_error(void);
  * newline, ROWS/COLS one 0-based int per line, VALS fixed with 17 digits after the point. */
 int pem_write_result_files(const char *dir, int64_t nnz, const int32_t *rows, const int32_t *cols, const double *vals);
 
+/* SURVEY 8(f)-1 (new, beyond the reference): write a CSR matrix as a Matrix-Market coordinate real general file,
+ * 1-based, rows ascending, columns ascending inside a row, values with 17 significant digits. */
+int pem_write_mtx_csr(const char *path, int32_t rows, int32_t cols, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                      const char *comment);
+
 /* spgemm.cu:1424-1450: append "\n" + the 14 reference fields (fixed, 2 decimals) to `path`;
  * `extra` (may be NULL) is appended verbatim after the 14th field. */
 typedef struct {

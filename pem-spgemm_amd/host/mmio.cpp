@@ -225,6 +225,28 @@ extern "C" int pem_write_result_files(const char *dir, int64_t nnz, const int32_
     return 0;
 }
 
+extern "C" int pem_write_mtx_csr(const char *path, int32_t rows, int32_t cols, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                                 const char *comment)
+{
+    if (!path || !rowptr || rows < 0 || cols < 0) { set_err("pem_write_mtx_csr: bad arguments"); return -1; }
+    FILE *f = fopen(path, "w");
+    if (!f) { set_err("cannot write %s: %s", path, strerror(errno)); return -1; }
+    std::vector<char> buf(1 << 22);
+    setvbuf(f, buf.data(), _IOFBF, buf.size());
+    fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n");
+    if (comment && *comment) fprintf(f, "%% %s\n", comment);
+    fprintf(f, "%d %d %lld\n", rows, cols, (long long)rowptr[rows]);
+    char num[40];
+    for (int32_t r = 0; r < rows; ++r)
+        for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+            auto res = std::to_chars(num, num + sizeof num, vals[e], std::chars_format::general, 17);
+            *res.ptr = 0;
+            fprintf(f, "%d %d %s\n", r + 1, colidx[e] + 1, num);
+        }
+    if (fclose(f) != 0) { set_err("write error on %s", path); return -1; }
+    return 0;
+}
+
 extern "C" int pem_csv_append(const char *path, const pem_csv_record *r, const char *extra)
 {
     FILE *f = fopen(path, "a");

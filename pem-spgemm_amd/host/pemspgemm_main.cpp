@@ -32,6 +32,18 @@ static int env_int(const char *name, int dflt)
 
 int main(int argc, char *argv[])
 {
+    // Beyond the reference: `--B <file.mtx>` multiplies by a second matrix instead of A itself,
+    // `--out <file.mtx>` writes C as a Matrix-Market file.  They are stripped before the reference's own grammar.
+    const char *b_path = nullptr, *out_path = nullptr;
+    {
+        int w = 1;
+        for (int r = 1; r < argc; ++r) {
+            if (!strcmp(argv[r], "--B") && r + 1 < argc) b_path = argv[++r];
+            else if (!strcmp(argv[r], "--out") && r + 1 < argc) out_path = argv[++r];
+            else argv[w++] = argv[r];
+        }
+        argc = w;
+    }
     if (argc <= 1 || argc > 4) {   // spgemm.cu:722-725
         printf("Provide a matrix market file path. Exiting.\n");
         return 1;
@@ -48,19 +60,36 @@ int main(int argc, char *argv[])
         fprintf(stderr, "pemspgemm: %s\n", pem_host_last_error());
         return 1;
     }
-    if (m.rows != m.cols && !aat) {   // spgemm.cu:782-786
+    pem_coo mb;
+    memset(&mb, 0, sizeof mb);
+    if (b_path) {
+        if (pem_mm_read(b_path, 0, &mb) != 0) {
+            fprintf(stderr, "pemspgemm: %s\n", pem_host_last_error());
+            return 1;
+        }
+        const int brows = aat ? mb.cols : mb.rows;
+        if (m.cols != brows) {
+            printf("inner dimensions differ: A is %d x %d, B%s is %d x %d. Exiting.\n", m.rows, m.cols, aat ? "^T" : "", brows,
+                   aat ? mb.rows : mb.cols);
+            return 1;
+        }
+    }
+    if (!b_path && m.rows != m.cols && !aat) {   // spgemm.cu:782-786
         printf("input is rectangular. Only AAt is possible. Exiting.\n");
         return 1;
     }
-    const int b_rows = aat ? m.cols : m.rows, b_cols = aat ? m.rows : m.cols;
+    const pem_coo &bsrc = b_path ? mb : m;
+    const int b_rows = aat ? bsrc.cols : bsrc.rows, b_cols = aat ? bsrc.rows : bsrc.cols;
     printf("MATRIX A\nfilepath: %s\nRows: %d\nCols: %d\nNnz: %lld\n", argv[1], m.rows, m.cols, (long long)m.nnz);   // spgemm.cu:794-806
-    printf("MATRIX B\nfilepath: %s\nRows: %d\nCols: %d\nNnz: %lld\n", argv[1], b_rows, b_cols, (long long)m.nnz);
+    printf("MATRIX B\nfilepath: %s\nRows: %d\nCols: %d\nNnz: %lld\n", b_path ? b_path : argv[1], b_rows, b_cols, (long long)bsrc.nnz);
 
     pem_ctx *ctx = nullptr;
     CHECK(pem_ctx_create(env_int("PEM_DEVICE", 0), &ctx));
     pem_tiled *A = nullptr, *B = nullptr;
     CHECK(pem_tiled_from_coo(ctx, m.rows, m.cols, m.nnz, m.I, m.J, m.V, 0, &A));
-    if (aat)
+    if (b_path)
+        CHECK(pem_tiled_from_coo(ctx, mb.rows, mb.cols, mb.nnz, mb.I, mb.J, mb.V, aat ? 1 : 0, &B));
+    else if (aat)
         CHECK(pem_tiled_from_coo(ctx, m.rows, m.cols, m.nnz, m.I, m.J, m.V, 1, &B));
     else
         B = A;   // the reference converts the same file twice (spgemm.cu:778-779); one tiling serves both roles here
@@ -155,11 +184,24 @@ int main(int argc, char *argv[])
             rc = 2;
         }
     }
+    if (out_path) {   // C as a Matrix-Market file (CSR export: rows ascending, columns ascending)
+        std::vector<int32_t> rp((size_t)(ci.row_end - ci.row_begin) + 1), cidx((size_t)ci.nnz_c);
+        std::vector<double> cv((size_t)ci.nnz_c);
+        int64_t nnz = 0;
+        CHECK(pem_c_export_csr(ctx, plan, &nnz, rp.data(), cidx.data(), cv.data()));
+        if (pem_write_mtx_csr(out_path, ia.rows, ib.cols, rp.data(), cidx.data(), cv.data(), "C = A*B by pemspgemm (pem-spgemm_amd)") != 0) {
+            fprintf(stderr, "pemspgemm: %s\n", pem_host_last_error());
+            rc = 2;
+        } else {
+            printf("C written to %s\n", out_path);
+        }
+    }
     printf("CLEANING UP RESOURCES\n\n");
     pem_cplan_destroy(ctx, plan);
     if (B != A) pem_tiled_destroy(ctx, B);
     pem_tiled_destroy(ctx, A);
     pem_ctx_destroy(ctx);
     pem_coo_free(&m);
+    pem_coo_free(&mb);
     return rc;
 }

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpemhost.so")
 CLI_PATH = os.path.join(_HERE, "pemspgemm")
 
-HOST_SYMBOLS = ["pem_mm_read", "pem_coo_free", "pem_host_last_error", "pem_write_result_files", "pem_csv_append"]
+HOST_SYMBOLS = ["pem_mm_read", "pem_coo_free", "pem_host_last_error", "pem_write_result_files", "pem_csv_append", "pem_write_mtx_csr"]
 
 
 class _Coo(C.Structure):
@@ -68,5 +68,15 @@ def csv_append(path, extra=None, **fields):
     for k, v in fields.items():
         setattr(rec, k, v.encode() if k == "matrix" else v)
     rc = lib().pem_csv_append(path.encode(), C.byref(rec), extra.encode() if extra else None)
+    if rc != 0:
+        raise RuntimeError(lib().pem_host_last_error().decode())
+
+
+def write_mtx_csr(path, rows, cols, rowptr, colidx, vals, comment=""):
+    rowptr = np.ascontiguousarray(rowptr, np.int32)
+    colidx = np.ascontiguousarray(colidx, np.int32)
+    vals = np.ascontiguousarray(vals, np.float64)
+    rc = lib().pem_write_mtx_csr(path.encode(), int(rows), int(cols), rowptr.ctypes.data_as(C.POINTER(C.c_int32)),
+                                 colidx.ctypes.data_as(C.POINTER(C.c_int32)), vals.ctypes.data_as(C.POINTER(C.c_double)), comment.encode())
     if rc != 0:
         raise RuntimeError(lib().pem_host_last_error().decode())

@@ -139,3 +139,31 @@ def test_full_size_against_cpu_port(pkg, oracle, standins, ctx, name, scale):
     plan.spgemm()
     rp2, ci2, v2 = plan.export_csr()
     assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(v2, v)
+
+
+def test_cli_distinct_b_and_mtx_output(pkg, oracle, standins, tmp_path):
+    """C = A*B with two files and a Matrix-Market result (beyond the reference's A^2 / A*A^T)."""
+    import scipy.io
+    hostio = importlib.import_module("pem_spgemm_amd.hostio")
+    rng = np.random.default_rng(3)
+    m, k, n = 70, 45, 90
+
+    def rand(r, c, nz):
+        key = rng.choice(r * c, nz, replace=False)
+        return (key // c).astype(np.int32), (key % c).astype(np.int32), rng.uniform(-1, 1, nz)
+
+    AI, AJ, AV = rand(m, k, 400)
+    BI, BJ, BV = rand(k, n, 380)
+    fa, fb, fc = str(tmp_path / "A.mtx"), str(tmp_path / "B.mtx"), str(tmp_path / "C.mtx")
+    standins.write_mtx(fa, m, k, AI, AJ, AV)
+    standins.write_mtx(fb, k, n, BI, BJ, BV)
+    env = dict(os.environ, PEM_CSV=str(tmp_path / "r.csv"), PEM_REPEAT="1")
+    out = subprocess.run([hostio.CLI_PATH, fa, "0", "--B", fb, "--out", fc], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr + out.stdout
+    rp, ci, v = oracle.csr_spgemm(oracle.Csr(m, k, AI, AJ, AV), oracle.Csr(k, n, BI, BJ, BV)).arrays()
+    C = scipy.io.mmread(fc).tocsr()
+    C.sort_indices()
+    assert C.shape == (m, n) and np.array_equal(C.indptr, rp) and np.array_equal(C.indices, ci) and np.array_equal(C.data, v)
+    # shape mismatch is refused
+    out = subprocess.run([hostio.CLI_PATH, fa, "0", "--B", fa], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 1 and "inner dimensions differ" in out.stdout

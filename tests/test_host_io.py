@@ -73,3 +73,20 @@ def test_csv_record_format(hostio, tmp_path):
     text = open(p).read()
     want = "\nwebbase-1M,69524195,51111996,1.36,1.23,2.00,300.46,1.00,2.50,3.25,7.00,6.75,0.25,19.86"
     assert text == want + want + ",1,42"   # "\n" + 14 fields, no header (spgemm.cu:1432-1448)
+
+
+def test_mtx_csr_writer_roundtrip(hostio, oracle, tmp_path):
+    import scipy.io
+    rng = np.random.default_rng(7)
+    rows, cols = 23, 31
+    key = rng.choice(rows * cols, 120, replace=False)
+    I, J, V = (key // cols).astype(np.int32), (key % cols).astype(np.int32), rng.uniform(-1, 1, 120)
+    rp, ci, v = oracle.Csr(rows, cols, I, J, V).arrays()
+    p = str(tmp_path / "c.mtx")
+    hostio.write_mtx_csr(p, rows, cols, rp, ci, v, "roundtrip")
+    M = scipy.io.mmread(p).tocsr()
+    M.sort_indices()
+    assert M.shape == (rows, cols) and np.array_equal(M.indptr, rp) and np.array_equal(M.indices, ci)
+    assert np.array_equal(M.data, v)                      # 17 significant digits: exact doubles
+    back = hostio.mm_read(p)
+    assert back["nnz"] == 120 and np.array_equal(back["V"], v)
