@@ -213,7 +213,7 @@ template <> __device__ __forceinline__ uint64_t s1_shfl_xor<uint64_t>(uint64_t v
 }
 
 template <typename KeyT, int THREADS, int EPT, int LOGT>
-__device__ __forceinline__ void s1_bitonic_regs(KeyT (&v)[EPT], KeyT *lds, const int tid)
+__device__ __forceinline__ void s1_bitonic_regs(KeyT (&v)[EPT], KeyT *lds, const int tid, const bool reverse = false)
 {
     constexpr int LOGE = EPT == 1 ? 0 : EPT == 2 ? 1 : EPT == 4 ? 2 : EPT == 8 ? 3 : EPT == 16 ? 4 : 5;
     constexpr int LOGNP = LOGT + LOGE;
@@ -262,7 +262,7 @@ __device__ __forceinline__ void s1_bitonic_regs(KeyT (&v)[EPT], KeyT *lds, const
         }
     }
 #pragma unroll
-    for (int m = 0; m < EPT; ++m) lds[m * THREADS + tid] = v[m];
+    for (int m = 0; m < EPT; ++m) lds[reverse ? (THREADS * EPT - 1 - (m * THREADS + tid)) : (m * THREADS + tid)] = v[m];
     __syncthreads();
 }
 
@@ -351,6 +351,32 @@ struct S1Row {
             }
         }
     }
+    // THREADS*16 < live keys <= THREADS*32: sort each half in registers (second half written back descending),
+    // which leaves one bitonic sequence; 15 merge stages in LDS finish it (a plain LDS bitonic sort needs 120)
+    template <int LOGT> __device__ __forceinline__ void sort_halves(const int tid) const
+    {
+        constexpr int HALF = THREADS * 16;
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {     // one copy of the sort code: two would double the register pressure
+            KeyT *half = keys + h * HALF;
+            KeyT v[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) v[m] = half[m * THREADS + tid];
+            __syncthreads();
+            s1_bitonic_regs<KeyT, THREADS, 16, LOGT>(v, half, tid, h == 1);
+        }
+        for (int jj = HALF; jj > 0; jj >>= 1) {
+            for (int t = tid; t < HALF; t += THREADS) {
+                const int lo = 2 * t - (t & (jj - 1)), hi = lo + jj;
+                const KeyT x = keys[lo], y = keys[hi];
+                if (x > y) {
+                    keys[lo] = y;
+                    keys[hi] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
     template <int EPT, int LOGT> __device__ __forceinline__ void sort_regs(const int tid) const
     {
         KeyT v[EPT];
@@ -428,6 +454,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
             row.template sort_regs<8, LOGT>(tid);
         else if (EMAX > 8 && nl <= THREADS * 16)
             row.template sort_regs<(EMAX > 8 ? 16 : 8), LOGT>(tid);
+        else if (EMAX == 32 && CAP == THREADS * 32)
+            row.template sort_halves<LOGT>(tid);      // keys are padded to CAP by expand_compact
         else
             row.sort_lds(tid, nl);
         // stream out the live products (the dead ones sorted behind them): sorted pairs, and per distinct tile
