@@ -253,9 +253,9 @@ extern "C" pem_status pem_ctx_create_on_stream(int device, void *stream, pem_ctx
     PEM_HIP(hipMemsetAsync(ctx->d_scalars, 0, sizeof(int64_t) * 64, ctx->stream));
     PEM_HIP(hipMemsetAsync(ctx->d_flags, 0, sizeof(int) * NUM_FLAGS, ctx->stream));
     for (auto &ev : ctx->ev) PEM_HIP(hipEventCreate(&ev));
-    PEM_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+    for (auto &a : ctx->aux) PEM_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
     PEM_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    PEM_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    for (auto &e : ctx->ev_join) PEM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     PEM_HIP(hipStreamSynchronize(ctx->stream));
     *out = ctx;
     return PEM_OK;
@@ -274,12 +274,14 @@ extern "C" pem_status pem_ctx_destroy(pem_ctx *ctx)
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->ev) (void)hipEventDestroy(e);
-    if (ctx->aux) {
-        (void)hipStreamSynchronize(ctx->aux);
-        (void)hipStreamDestroy(ctx->aux);
-    }
+    for (auto a : ctx->aux)
+        if (a) {
+            (void)hipStreamSynchronize(a);
+            (void)hipStreamDestroy(a);
+        }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    for (auto e : ctx->ev_join)
+        if (e) (void)hipEventDestroy(e);
     (void)hipHostFree(ctx->h_scalars);
     (void)hipFree(ctx->d_scalars);
     (void)hipFree(ctx->d_flags);

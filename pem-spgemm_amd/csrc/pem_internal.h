@@ -94,8 +94,8 @@ struct pem_ctx {
     // timing
     hipEvent_t ev[8] = {};             // step spans
     // fork/join inside a step: an independent long-tailed kernel runs on an auxiliary stream
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t aux[3] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {};
     pem_timings timings = {};
     bool profiling = false;
     std::vector<pem::KernelStat> stats;

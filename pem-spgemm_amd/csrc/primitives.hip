@@ -216,6 +216,53 @@ __global__ void scan_empty_kernel(int *out, long long *total64)
     if (total64) *total64 = 0;
 }
 
+// short arrays (row counts of a slice, histogram tails): one 1024-thread block does the whole scan in one launch
+constexpr size_t SCAN_SMALL = 65536;
+__global__ void __launch_bounds__(1024) scan_small_kernel(const int *in, int *out, size_t n, long long *__restrict__ total64,
+                                                          int *__restrict__ flags)
+{
+    __shared__ int wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long carry = 0;
+    for (size_t base = 0; base < n; base += 4096) {
+        const size_t i0 = base + (size_t)threadIdx.x * 4;
+        int v[4];
+        if (i0 + 4 <= n) {
+            const int4 q = *reinterpret_cast<const int4 *>(in + i0);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? in[i0 + k] : 0;
+        }
+        const int tsum = v[0] + v[1] + v[2] + v[3];
+        const int inc = wave_inclusive_scan(tsum);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int woff = 0, btotal = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int c = wsum[w];
+            if (w < wave) woff += c;
+            btotal += c;
+        }
+        const int o0 = (int)carry + woff + inc - tsum, o1 = o0 + v[0], o2 = o1 + v[1], o3 = o2 + v[2];
+        if (i0 + 4 <= n) {
+            *reinterpret_cast<int4 *>(out + i0) = make_int4(o0, o1, o2, o3);
+        } else {
+            if (i0 < n) out[i0] = o0;
+            if (i0 + 1 < n) out[i0 + 1] = o1;
+            if (i0 + 2 < n) out[i0 + 2] = o2;
+        }
+        carry += btotal;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[n] = (int)carry;
+        if (total64) *total64 = carry;
+        if (carry > 0x7FFFFFFFLL) flags[FLAG_OVERFLOW] = 1;
+    }
+}
+
 pem_status exclusive_scan_i32(pem_ctx *ctx, const int *in, int *out, size_t n, int64_t *d_total64)
 {
     if (n == 0) {
@@ -225,6 +272,10 @@ pem_status exclusive_scan_i32(pem_ctx *ctx, const int *in, int *out, size_t n, i
     if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) {
         set_error("exclusive_scan_i32: unaligned pointer");
         return PEM_E_INVALID;
+    }
+    if (n <= SCAN_SMALL) {
+        PEM_LAUNCH(ctx, scan_small_kernel, 1, 1024, in, out, n, reinterpret_cast<long long *>(d_total64), ctx->d_flags);
+        return PEM_OK;
     }
     int nblk = (int)((n + SCAN_BLOCK_ITEMS - 1) / SCAN_BLOCK_ITEMS);
     PEM_TRY(ctx->scan_bsum.reserve(sizeof(long long) * ((size_t)nblk + 1)));

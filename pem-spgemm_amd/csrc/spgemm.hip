@@ -6,13 +6,16 @@
 // (spgemm.cu:499-591); step 3 numeric with a global read-modify-write per product
 // (spgemm.cu:593-661).
 //
-// Here (v0 of the MI355X design): the tile-level product is expanded once -- every
-// (A tile, B tile) pair with matching k is a product with key (C tile row, C tile col) --
-// and ONE stable radix sort groups the products by C tile in ascending k.  The C tile list
-// (step 1) and the pair lists (step 2a/2b) are two views of that sorted stream: no SPA, no
-// hash tables, no binary searches, nothing computed twice.  Step 2c uses the boolean row
-// product (C row r = OR of B rows kk over kk in A row r) on 16-lane groups; step 3 keeps one
-// C entry per lane in a register and stores it once.  All outputs keep the reference layouts.
+// Here: every (A tile (i,k), B tile (k,j)) with matching k is a *product* of tile row i keyed by j, so grouping
+// a row's products by j yields the C tile list (step 1) and the pair lists in ascending k (step 2a/2b) in one
+// pass -- no SPA, no hash tables, no binary searches, nothing computed twice.  Products whose tiles cannot
+// meet (A tile's occupied columns miss B tile's occupied rows) are dropped up front (exact; PEM_PRUNE=0 keeps
+// the reference's lists).  Default path: per-row LDS/register bitonic sorts, binned by row size; the global
+// expand + radix-sort path ("esc") serves oversized rows and PEM_STEP1=esc.  Step 2c is the boolean row
+// product (C row r = OR of B rows kk over kk in A row r), one C tile per lane; step 3 keeps one C entry per
+// lane in a register, accumulates in ascending k with one fma per product, and stores once.  All outputs keep
+// the reference layouts (include/pem_spgemm.h).  Environment switches (A/B baselines kept for tests):
+//   PEM_STEP1=esc  PEM_WIDE=0  PEM_PRUNE=0  PEM_NO_WARM=1  PEM_EXPORT=rows
 #include "pem_internal.h"
 #include <chrono>
 
@@ -1212,26 +1215,42 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
                          A->tile_occ.as<uint32_t>(), B->tile_occ.as<uint32_t>(), prune, p->pairs_a.as<int>(), p->pairs_b.as<int>(),   \
                          p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->c_tile_rowptr.as<int>());                             \
     }
-    // The largest bin is a handful of rows, one 1024-thread block per CU, each running long: fork it onto the
-    // auxiliary stream so the other bins fill the rest of the chip meanwhile; joined before the row-count scan.
-    bool forked = false;
+    // The bins are independent.  The largest is a handful of long-running single-CU blocks, and on small inputs
+    // every bin is tail-bound: fork bins 3, 2, 1 onto auxiliary streams next to bin 0 on the main stream so they
+    // fill each other's gaps; joined before the row-count scan.
+    hipStream_t main_stream = ctx->stream;
+    (void)hipEventRecord(ctx->ev_fork, main_stream);
+    bool forked[3] = {false, false, false};
+    auto fork_begin = [&](int k) {
+        (void)hipStreamWaitEvent(ctx->aux[k], ctx->ev_fork, 0);
+        ctx->stream = ctx->aux[k];
+        forked[k] = true;
+    };
+    auto fork_end = [&](int k) {
+        (void)hipEventRecord(ctx->ev_join[k], ctx->aux[k]);
+        ctx->stream = main_stream;
+    };
     if constexpr (sizeof(KeyT) == 4) {
         if (cap3 > S1_CAP2 && counts[3] > 0) {
-            hipStream_t main_stream = ctx->stream;
-            (void)hipEventRecord(ctx->ev_fork, main_stream);
-            (void)hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0);
-            ctx->stream = ctx->aux;
+            fork_begin(0);
             PEM_ROWSORT(3, 32768, QBITS, 1024, 2048, 1 << 20)
-            (void)hipEventRecord(ctx->ev_join, ctx->aux);
-            ctx->stream = main_stream;
-            forked = true;
+            fork_end(0);
         }
     }
-    PEM_ROWSORT(2, 8192, QBITS, 1024, 2048, 1 << 20)
-    PEM_ROWSORT(1, 2048, QBITS, 256, 1024, 1 << 20)
+    if (counts[2] > 0) {
+        fork_begin(1);
+        PEM_ROWSORT(2, 8192, QBITS, 1024, 2048, 1 << 20)
+        fork_end(1);
+    }
+    if (counts[1] > 0) {
+        fork_begin(2);
+        PEM_ROWSORT(1, 2048, QBITS, 256, 1024, 1 << 20)
+        fork_end(2);
+    }
     PEM_ROWSORT(0, 512, QBITS, 64, 256, 1 << 20)
 #undef PEM_ROWSORT
-    if (forked) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+    for (int k = 0; k < 3; ++k)
+        if (forked[k]) (void)hipStreamWaitEvent(main_stream, ctx->ev_join[k], 0);
 }
 
 static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
