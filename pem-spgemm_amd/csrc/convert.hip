@@ -95,7 +95,7 @@ __global__ void conv_fill_kernel(const uint64_t *__restrict__ keys, const uint32
 __global__ void __launch_bounds__(256) conv_tile_meta_kernel(const uint8_t *__restrict__ rowcolidx, const int *__restrict__ tile_nnz_ptr,
                                                              long long ntiles, uint16_t *__restrict__ masks, uint8_t *__restrict__ rowptr,
                                                              uint16_t *__restrict__ masks_t, uint32_t *__restrict__ rec,
-                                                             uint32_t *__restrict__ occ)
+                                                             uint32_t *__restrict__ occ, uint32_t *__restrict__ rec_t)
 {
     long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int r = threadIdx.x & 15;
@@ -130,12 +130,36 @@ __global__ void __launch_bounds__(256) conv_tile_meta_kernel(const uint8_t *__re
     const unsigned long long nzrows = __ballot(mask != 0);
     const unsigned ro = (unsigned)(nzrows >> (16 * grp)) & 0xFFFFu;
     if (live && r == 0) occ[t] = co | (ro << 16);
+    // transposed record of column c = r: rows holding it | number of entries in the columns before it
+    int ccnt = __popc(bt), cinc = ccnt;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        int v = __shfl_up(cinc, d, 16);
+        if (r >= d) cinc += v;
+    }
+    if (live) rec_t[16 * t + r] = bt | ((unsigned)(cinc - ccnt) << 16);
     if (live) {
         masks[16 * t + r] = (uint16_t)mask;
         rowptr[16 * t + r] = (uint8_t)(inc - cnt);
         masks_t[16 * t + r] = (uint16_t)bt;
         rec[16 * t + r] = mask | ((unsigned)(inc - cnt) << 16);
     }
+}
+
+// column-major copy of every tile's values: entry (rr, c) of tile t goes to slot (entries in columns < c) + (rows < rr
+// holding column c).  headx = exclusive scan of the tile-head flags (tile of entry e = headx[e] - !is_head).
+__global__ void conv_vals_t_kernel(const uint8_t *__restrict__ rowcolidx, const double *__restrict__ vals, const int *__restrict__ headx,
+                                   size_t nnz, const int *__restrict__ tile_nnz_ptr, const uint32_t *__restrict__ rec_t,
+                                   double *__restrict__ vals_t)
+{
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const int hx = headx[e];
+    const int t = (headx[e + 1] != hx) ? hx : hx - 1;
+    const unsigned rc = rowcolidx[e];
+    const unsigned rr = rc >> 4, c = rc & 15u;
+    const unsigned w = rec_t[16 * (size_t)t + c];
+    vals_t[tile_nnz_ptr[t] + (int)(w >> 16) + __popc(w & 0xFFFFu & ((1u << rr) - 1u))] = vals[e];
 }
 
 // a7 (spgemm.cu:986-1031): tile-level CSR from the sorted tile list -- boundary fill, no
@@ -382,6 +406,8 @@ static pem_status build_tiled(pem_ctx *ctx, pem_tiled *T, DevBuf &k0, DevBuf &k1
     PEM_TRY(T->rowptr.reserve(16 * (nt + 1)));
     PEM_TRY(T->tile_rec.reserve(sizeof(uint32_t) * 16 * (nt + 1)));
     PEM_TRY(T->tile_occ.reserve(sizeof(uint32_t) * (nt + 4)));
+    PEM_TRY(T->tile_rec_t.reserve(sizeof(uint32_t) * 16 * (nt + 1)));
+    PEM_TRY(T->vals_t.reserve(sizeof(double) * (nnz + 1)));
     PEM_TRY(T->tile_rowptr.reserve(sizeof(int) * ((size_t)T->tile_rows + 4)));
     PEM_TRY(T->tile_colidx.reserve(sizeof(int) * (nt + 4)));
     PEM_TRY(T->tile_colptr.reserve(sizeof(int) * ((size_t)T->tile_cols + 4)));
@@ -396,8 +422,11 @@ static pem_status build_tiled(pem_ctx *ctx, pem_tiled *T, DevBuf &k0, DevBuf &k1
                    T->rowcolidx.as<uint8_t>(), T->tile_keys.as<long long>(), T->tile_nnz_ptr.as<int>());
         PEM_LAUNCH(ctx, conv_tile_meta_kernel, grid_for(nt * 16, 256), 256, T->rowcolidx.as<uint8_t>(), T->tile_nnz_ptr.as<int>(),
                    (long long)ntiles, T->masks.as<uint16_t>(), T->rowptr.as<uint8_t>(), T->masks_t.as<uint16_t>(), T->tile_rec.as<uint32_t>(),
-                   T->tile_occ.as<uint32_t>());
+                   T->tile_occ.as<uint32_t>(), T->tile_rec_t.as<uint32_t>());
     }
+    if (nnz)
+        PEM_LAUNCH(ctx, conv_vals_t_kernel, grid_for(nnz, 256), 256, T->rowcolidx.as<uint8_t>(), T->vals.as<double>(), head.as<int>(), nnz,
+                   T->tile_nnz_ptr.as<int>(), T->tile_rec_t.as<uint32_t>(), T->vals_t.as<double>());
     PEM_HIP(hipEventRecord(ctx->ev[7], st));
     if (nt) {
         PEM_LAUNCH(ctx, conv_tile_csr_kernel, grid_for(nt, 256), 256, T->tile_keys.as<long long>(), (long long)ntiles, T->tile_rows,

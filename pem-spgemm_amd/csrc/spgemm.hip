@@ -433,7 +433,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
         row.p0 = aprod_off[row.a0];
         row.n = aprod_off[row.a1] - row.p0;
         row.staged = row.R <= RCAP;   // the row's A-tile table fits in LDS (else: search it in global memory)
-        const int n = row.n, p0 = row.p0;
+        const int p0 = row.p0;
         if (row.staged) {
             for (int x = tid; x <= row.R; x += THREADS) {
                 roff[x] = aprod_off[row.a0 + x] - p0;
@@ -783,8 +783,7 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b, long long ntc,
     const int *__restrict__ c_tile_nnz_ptr, long long nnz_c, const uint8_t *__restrict__ c_rowcolidx, double *__restrict__ c_vals,
     const int *__restrict__ a_nnz_ptr, const double *__restrict__ a_vals, const uint32_t *__restrict__ a_rec,
-    const int *__restrict__ b_nnz_ptr, const double *__restrict__ b_vals, const uint32_t *__restrict__ b_rec,
-    const uint16_t *__restrict__ b_masks_t)
+    const int *__restrict__ b_nnz_ptr, const double *__restrict__ b_vals_t, const uint32_t *__restrict__ b_rec_t)
 {
     // Work is dealt by ENTRIES, S3_EPW per wave, so hub rows (tiles with many entries and pairs) cannot pile
     // up in one wave.  The wave finds its first tile with a 64-ary search (one gather + ballot per level),
@@ -833,23 +832,24 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
         if (!valid) continue;
         const unsigned rc = c_rowcolidx[e];
         const int r = rc >> 4, c = rc & 15;
-        const unsigned clt = (1u << c) - 1u;
         double acc = 0.0;
         for (int p = p0; p < p1; ++p) {
             const int a = pairs_a[p], b = pairs_b[p];
             const unsigned aw = a_rec[16 * (size_t)a + r];
             const unsigned am = aw & 0xFFFFu;
-            unsigned m = am & (unsigned)b_masks_t[16 * (size_t)b + c];
+            // B is read by column here: its transposed record (rows holding column c | entries in the columns before)
+            // and its column-major values give every operand with one record gather + one value gather per product
+            const unsigned bw = b_rec_t[16 * (size_t)b + c];
+            const unsigned bm = bw & 0xFFFFu;
+            unsigned m = am & bm;
             if (!m) continue;
             const double *av = a_vals + a_nnz_ptr[a] + (aw >> 16);
-            const double *bv = b_vals + b_nnz_ptr[b];
+            const double *bv = b_vals_t + b_nnz_ptr[b] + (bw >> 16);
             while (m) {
                 const int kk = __builtin_ctz(m);
                 m &= m - 1;
-                const unsigned bw = b_rec[16 * (size_t)b + kk];
-                const int ao = __popc(am & ((1u << kk) - 1u));
-                const int bo = __popc(bw & clt);
-                acc = __builtin_fma(av[ao], bv[(bw >> 16) + bo], acc);
+                const unsigned below = (1u << kk) - 1u;
+                acc = __builtin_fma(av[__popc(am & below)], bv[__popc(bm & below)], acc);
             }
         }
         c_vals[e] = acc;
@@ -1467,8 +1467,7 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_LAUNCH(ctx, s3_accumulate_wide_kernel, grid_for(((size_t)p->nnz_c + S3_EPW - 1) / S3_EPW * 64, 256), 256, p->pairs_offset.as<int>(),
                    p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(), (long long)p->nnz_c,
                    p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<double>(), A->tile_nnz_ptr.as<int>(),
-                   A->vals.as<double>(), A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals.as<double>(), B->tile_rec.as<uint32_t>(),
-                   B->masks_t.as<uint16_t>());
+                   A->vals.as<double>(), A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<double>(), B->tile_rec_t.as<uint32_t>());
     else if (ntc > 0)
         PEM_LAUNCH(ctx, s3_accumulate_kernel, grid_for(ntc * 16, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
                    (long long)ntc, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<double>(), A->tile_nnz_ptr.as<int>(),
