@@ -218,6 +218,10 @@ template <> __device__ __forceinline__ uint64_t s1_shfl_xor<uint64_t>(uint64_t v
 template <typename KeyT, int THREADS, int EPT, int LOGT>
 __device__ __forceinline__ void s1_bitonic_regs(KeyT (&v)[EPT], KeyT *lds, const int tid, const bool reverse = false)
 {
+    // Blocked layout: element e = tid*EPT + m.  The log2(EPT) SMALLEST strides -- which every merge level runs --
+    // are then exchanges between registers of one thread, the next six are wave shuffles (lane ^ jj/EPT) and only
+    // strides >= 64*EPT cross waves through LDS (3 of the 66 stages at 2048 keys; the strided layout e = m*T + tid
+    // made the LARGEST strides register-local, which only the last levels have, and needed 9 LDS + 39 shuffle stages).
     constexpr int LOGE = EPT == 1 ? 0 : EPT == 2 ? 1 : EPT == 4 ? 2 : EPT == 8 ? 3 : EPT == 16 ? 4 : 5;
     constexpr int LOGNP = LOGT + LOGE;
 #pragma unroll
@@ -226,37 +230,38 @@ __device__ __forceinline__ void s1_bitonic_regs(KeyT (&v)[EPT], KeyT *lds, const
 #pragma unroll
         for (int lj = lk - 1; lj >= 0; --lj) {
             const int jj = 1 << lj;
-            if (lj >= LOGT) {            // partner in another register of this thread
-                const int dm = jj / THREADS;
+            if (lj < LOGE) {             // partner in another register of this thread
 #pragma unroll
                 for (int m = 0; m < EPT; ++m) {
-                    if ((m & dm) == 0 && (m | dm) < EPT) {
-                        const int m2 = m | dm;
-                        const bool up = (((m * THREADS) | tid) & kk) == 0;
+                    if ((m & jj) == 0) {
+                        const int m2 = m | jj;
+                        const bool up = (((tid << LOGE) | m) & kk) == 0;
                         const KeyT x = v[m], y = v[m2];
                         const bool sw = (x > y) == up;
                         v[m] = sw ? y : x;
                         v[m2] = sw ? x : y;
                     }
                 }
-            } else if (lj < 6) {         // partner in another lane of this wave
+            } else if (lj < LOGE + 6) {  // partner in another lane of this wave
+                const int lm = jj >> LOGE;
+                const bool lower = (tid & lm) == 0;
 #pragma unroll
                 for (int m = 0; m < EPT; ++m) {
-                    const KeyT pv = s1_shfl_xor<KeyT>(v[m], jj);
-                    const bool up = (((m * THREADS) | tid) & kk) == 0;
-                    const bool lower = (tid & jj) == 0;
+                    const KeyT pv = s1_shfl_xor<KeyT>(v[m], lm);
+                    const bool up = (((tid << LOGE) | m) & kk) == 0;
                     const KeyT mn = v[m] < pv ? v[m] : pv, mx = v[m] < pv ? pv : v[m];
                     v[m] = (lower == up) ? mn : mx;
                 }
-            } else {                     // partner in another wave: through LDS
+            } else {                     // partner in another wave: through LDS ([m][tid] image: conflict-free)
+                const int tm = jj >> LOGE;
+                const bool lower = (tid & tm) == 0;
 #pragma unroll
                 for (int m = 0; m < EPT; ++m) lds[m * THREADS + tid] = v[m];
                 __syncthreads();
 #pragma unroll
                 for (int m = 0; m < EPT; ++m) {
-                    const KeyT pv = lds[(m * THREADS + tid) ^ jj];
-                    const bool up = (((m * THREADS) | tid) & kk) == 0;
-                    const bool lower = (tid & jj) == 0;
+                    const KeyT pv = lds[m * THREADS + (tid ^ tm)];
+                    const bool up = (((tid << LOGE) | m) & kk) == 0;
                     const KeyT mn = v[m] < pv ? v[m] : pv, mx = v[m] < pv ? pv : v[m];
                     v[m] = (lower == up) ? mn : mx;
                 }
@@ -265,7 +270,7 @@ __device__ __forceinline__ void s1_bitonic_regs(KeyT (&v)[EPT], KeyT *lds, const
         }
     }
 #pragma unroll
-    for (int m = 0; m < EPT; ++m) lds[reverse ? (THREADS * EPT - 1 - (m * THREADS + tid)) : (m * THREADS + tid)] = v[m];
+    for (int m = 0; m < EPT; ++m) lds[reverse ? (THREADS * EPT - 1 - ((tid << LOGE) | m)) : ((tid << LOGE) | m)] = v[m];
     __syncthreads();
 }
 
