@@ -146,6 +146,9 @@ inline int bits_for(uint64_t count)   // bits needed to represent values in [0, 
 // If d_total64 != nullptr the 64-bit total is also stored there.
 pem_status exclusive_scan_i32(pem_ctx *ctx, const int *in, int *out, size_t n, int64_t *d_total64);
 
+// two arrays of equal length scanned in place by one set of launches
+pem_status exclusive_scan_i32_pair(pem_ctx *ctx, int *a, int *b, size_t n, int64_t *d_total_a, int64_t *d_total_b);
+
 // Stable LSD radix sort of (key, payload) on key bits [0, nbits).  Buffers ping-pong; on
 // return *keys_out / *vals_out point at the buffers holding the sorted data.
 pem_status radix_sort_u64_u32(pem_ctx *ctx, uint64_t *k0, uint64_t *k1, uint32_t *v0, uint32_t *v1,

@@ -286,6 +286,127 @@ pem_status exclusive_scan_i32(pem_ctx *ctx, const int *in, int *out, size_t n, i
     return PEM_OK;
 }
 
+// Two independent arrays of the same length scanned by one set of launches (blockIdx.y picks the array).
+struct ScanPair {
+    const int *in[2];
+    int *out[2];
+    long long *bsum[2];
+    long long *total64[2];
+};
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan2_reduce_kernel(ScanPair sp, size_t n)
+{
+    __shared__ long long wsum[SCAN_THREADS / 64];
+    const int *in = sp.in[blockIdx.y];
+    size_t base = (size_t)blockIdx.x * SCAN_BLOCK_ITEMS;
+    size_t end = base + SCAN_BLOCK_ITEMS < n ? base + SCAN_BLOCK_ITEMS : n;
+    long long s = 0;
+    for (size_t i = base + threadIdx.x; i < end; i += SCAN_THREADS) s += in[i];
+    s = wave_reduce_sum(s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) t += wsum[w];
+        sp.bsum[blockIdx.y][blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(1024) scan2_bsums_kernel(ScanPair sp, int nblk, int *__restrict__ flags)
+{
+    __shared__ long long wsum[16];
+    __shared__ long long carry_s;
+    long long *bsum = sp.bsum[blockIdx.x];
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        int i = base + threadIdx.x;
+        long long v = i < nblk ? bsum[i] : 0;
+        long long inc = wave_inclusive_scan(v);
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        long long woff = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+        long long carry = carry_s;
+        if (i < nblk) bsum[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        long long t = carry_s;
+        bsum[nblk] = t;
+        if (sp.total64[blockIdx.x]) *sp.total64[blockIdx.x] = t;
+        if (t > 0x7FFFFFFFLL) flags[FLAG_OVERFLOW] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan2_apply_kernel(ScanPair sp, size_t n, int nblk)
+{
+    __shared__ int wsum[SCAN_THREADS / 64];
+    const int *in = sp.in[blockIdx.y];
+    int *out = sp.out[blockIdx.y];
+    const long long *bsum = sp.bsum[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long carry = bsum[blockIdx.x];
+    size_t base = (size_t)blockIdx.x * SCAN_BLOCK_ITEMS;
+    for (int tile = 0; tile < SCAN_TILES_PER_BLOCK; ++tile, base += SCAN_TILE) {
+        if (base >= n) break;
+        size_t i0 = base + (size_t)threadIdx.x * 4;
+        int v[4];
+        if (i0 + 4 <= n) {
+            int4 q = *reinterpret_cast<const int4 *>(in + i0);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? in[i0 + k] : 0;
+        }
+        int tsum = v[0] + v[1] + v[2] + v[3];
+        int inc = wave_inclusive_scan(tsum);
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int woff = 0, btotal = 0;
+#pragma unroll
+        for (int w = 0; w < SCAN_THREADS / 64; ++w) {
+            int c = wsum[w];
+            if (w < wave) woff += c;
+            btotal += c;
+        }
+        int o0 = (int)carry + woff + inc - tsum, o1 = o0 + v[0], o2 = o1 + v[1], o3 = o2 + v[2];
+        if (i0 + 4 <= n) {
+            *reinterpret_cast<int4 *>(out + i0) = make_int4(o0, o1, o2, o3);
+        } else {
+            if (i0 < n) out[i0] = o0;
+            if (i0 + 1 < n) out[i0 + 1] = o1;
+            if (i0 + 2 < n) out[i0 + 2] = o2;
+        }
+        carry += btotal;
+        __syncthreads();
+    }
+    if (blockIdx.x == nblk - 1 && threadIdx.x == 0) out[n] = (int)bsum[nblk];
+}
+
+pem_status exclusive_scan_i32_pair(pem_ctx *ctx, int *a, int *b, size_t n, int64_t *d_total_a, int64_t *d_total_b)
+{
+    if (n <= SCAN_SMALL) {   // short: two single-launch scans
+        PEM_TRY(exclusive_scan_i32(ctx, a, a, n, d_total_a));
+        return exclusive_scan_i32(ctx, b, b, n, d_total_b);
+    }
+    int nblk = (int)((n + SCAN_BLOCK_ITEMS - 1) / SCAN_BLOCK_ITEMS);
+    PEM_TRY(ctx->scan_bsum.reserve(sizeof(long long) * 2 * ((size_t)nblk + 2)));
+    ScanPair sp;
+    sp.in[0] = a; sp.in[1] = b;
+    sp.out[0] = a; sp.out[1] = b;
+    sp.bsum[0] = ctx->scan_bsum.as<long long>();
+    sp.bsum[1] = sp.bsum[0] + nblk + 2;
+    sp.total64[0] = reinterpret_cast<long long *>(d_total_a);
+    sp.total64[1] = reinterpret_cast<long long *>(d_total_b);
+    PEM_LAUNCH(ctx, scan2_reduce_kernel, dim3(nblk, 2), SCAN_THREADS, sp, n);
+    PEM_LAUNCH(ctx, scan2_bsums_kernel, 2, 1024, sp, nblk, ctx->d_flags);
+    PEM_LAUNCH(ctx, scan2_apply_kernel, dim3(nblk, 2), SCAN_THREADS, sp, n, nblk);
+    return PEM_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // LSD radix sort, 8 bits per pass, stable.  Per pass: block histograms -> device scan ->
 // scatter.  A block = 4 waves x 16 rounds x 64 keys; ranks come from wave64 ballots

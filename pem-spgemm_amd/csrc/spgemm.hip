@@ -163,6 +163,19 @@ __global__ void s1_c_rowptr_kernel(const int *__restrict__ c_rowidx, long long n
 // ------------------------------------------------------------------------------------------
 constexpr int S1_CAP0 = 512, S1_CAP1 = 2048, S1_CAP2 = 8192, S1_CAP3 = 32768;
 
+__global__ void s1_reset_kernel(int *__restrict__ flags, int *__restrict__ bin_count, long long *__restrict__ scalars,
+                                int *__restrict__ pairs_offset, int *__restrict__ row_tc, int mt)
+{
+    const int i = threadIdx.x;
+    if (i < NUM_FLAGS) flags[i] = 0;
+    if (i < 8) bin_count[i] = 0;
+    if (i < 4) scalars[i] = 0;
+    if (i == 0) {
+        pairs_offset[0] = 0;
+        row_tc[mt] = 0;
+    }
+}
+
 __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int mt, int a_lo,
                                                           const int *__restrict__ aprod_off, const int *__restrict__ lprod_off, int cap3,
                                                           int qcap, int *__restrict__ row_list,
@@ -283,31 +296,36 @@ struct S1Row {
     int R, a0, a1, p0, n, a_lo, prune;
     const int *a_tile_colidx, *aprod_off, *b_tile_rowptr, *b_tile_colidx;
     const uint32_t *a_occ, *b_occ;
-    __device__ __forceinline__ int tile_b(int q, int *a_out, unsigned *acol_out = nullptr) const
+    struct Product {
+        int a, b;          // operand tile ids
+        unsigned acol;     // occupied columns of the A tile
+    };
+    // by value: address-taken locals would put the kernel on a scratch (private memory) segment
+    __device__ __forceinline__ Product tile_b(int q, bool want_acol) const
     {
-        int ar, b;
+        Product r;
+        int ar;
+        r.acol = 0xFFFFu;
         if (staged) {
             ar = s1_find_a(roff, 0, R, q);
-            b = rbs[ar] + (q - roff[ar]);
-            if (acol_out) *acol_out = rco[ar];
+            r.b = rbs[ar] + (q - roff[ar]);
+            if (want_acol) r.acol = rco[ar];
             ar += a0;
         } else {
             ar = s1_find_a(aprod_off, a0, a1, p0 + q);
-            b = b_tile_rowptr[a_tile_colidx[a_lo + ar]] + (p0 + q - aprod_off[ar]);
-            if (acol_out) *acol_out = a_occ[a_lo + ar] & 0xFFFFu;
+            r.b = b_tile_rowptr[a_tile_colidx[a_lo + ar]] + (p0 + q - aprod_off[ar]);
+            if (want_acol) r.acol = a_occ[a_lo + ar] & 0xFFFFu;
         }
-        *a_out = a_lo + ar;
-        return b;
+        r.a = a_lo + ar;
+        return r;
     }
     // key of product q: (tile col, q); a product whose tiles cannot meet gets the padding key and sorts to the end
     __device__ __forceinline__ KeyT product_key(int q) const
     {
         if (q >= n) return ~KeyT(0);
-        int a;
-        unsigned acol = 0xFFFFu;
-        const int b = tile_b(q, &a, prune ? &acol : nullptr);
-        if (prune && !(acol & (b_occ[b] >> 16))) return ~KeyT(0);
-        return (KeyT(b_tile_colidx[b]) << QB) | KeyT(q);
+        const Product pr = tile_b(q, prune != 0);
+        if (prune && !(pr.acol & (b_occ[pr.b] >> 16))) return ~KeyT(0);
+        return (KeyT(b_tile_colidx[pr.b]) << QB) | KeyT(q);
     }
     // expand all n products of the row, keep the live ones: their keys are packed into keys[0..nlive) in
     // arbitrary order (ballot + one LDS atomic per wave and chunk) -- the sort that follows fixes the order,
@@ -316,16 +334,24 @@ struct S1Row {
     {
         const int lane = tid & 63;
         const unsigned long long lt = (1ull << lane) - 1ull;
-        for (int q0 = 0; q0 < n; q0 += THREADS) {
-            const KeyT key = product_key(q0 + tid);
-            const bool live = key != ~KeyT(0);
-            const unsigned long long bal = __ballot(live);
-            if (bal) {
-                int base = 0;
-                const int leader = __builtin_ctzll(bal);
-                if (lane == leader) base = atomicAdd(s_cnt, __popcll(bal));
-                base = __shfl(base, leader, 64);
-                if (live) keys[base + __popcll(bal & lt)] = key;
+        // four chunks per trip: their table searches and B-side gathers are independent and overlap; the
+        // compaction (ballot + one LDS atomic per wave and chunk) follows once the keys are in registers
+        constexpr int U = 4;
+        for (int q0 = 0; q0 < n; q0 += U * THREADS) {
+            KeyT key[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) key[u] = product_key(q0 + u * THREADS + tid);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool live = key[u] != ~KeyT(0);
+                const unsigned long long bal = __ballot(live);
+                if (bal) {
+                    int base = 0;
+                    const int leader = __builtin_ctzll(bal);
+                    if (lane == leader) base = atomicAdd(s_cnt, __popcll(bal));
+                    base = __shfl(base, leader, 64);
+                    if (live) keys[base + __popcll(bal & lt)] = key[u];
+                }
             }
         }
         __syncthreads();
@@ -395,6 +421,41 @@ struct S1Row {
     }
 };
 
+#ifdef PEM_S1_DEBUG
+// diagnostic build only (make EXTRA=-DPEM_S1_DEBUG): phase clocks of the row-sort bins, spread over 1024 slots per
+// bin so the bookkeeping atomics do not serialise; [bin][slot][stage, expand, sort, emit, rows, max row, -, -]
+__device__ unsigned long long g_s1dbg[4][1024][8];
+__device__ unsigned long long g_s1blk[4][1024][4];   // first 1024 blocks of every bin: start, end, HW_ID, XCC_ID
+extern "C" void pem_debug_s1_blocks(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s1blk), sizeof(unsigned long long) * 4 * 1024 * 4); }
+#define S1_DBG_MARK(k)                                                   \
+    do {                                                                 \
+        __syncthreads();                                                 \
+        if (tid == 0) {                                                  \
+            unsigned long long now = wall_clock64();                     \
+            atomicAdd(&g_s1dbg[DBG_BIN][blockIdx.x & 1023][k], now - dbg_t); \
+            dbg_t = now;                                                 \
+        }                                                                \
+    } while (0)
+extern "C" void pem_debug_s1(unsigned long long *out32, int reset)
+{
+    static unsigned long long h[4][1024][8];
+    if (reset) {
+        memset(h, 0, sizeof(h));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_s1dbg), h, sizeof(h));
+    } else {
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_s1dbg), sizeof(h));
+        for (int b = 0; b < 4; ++b)
+            for (int k = 0; k < 8; ++k) {
+                unsigned long long acc = 0;
+                for (int sl = 0; sl < 1024; ++sl) acc = k == 5 ? (h[b][sl][k] > acc ? h[b][sl][k] : acc) : acc + h[b][sl][k];
+                out32[b * 8 + k] = acc;
+            }
+    }
+}
+#else
+#define S1_DBG_MARK(k)
+#endif
+
 template <typename KeyT, int CAP, int QB, int THREADS, int RCAP>
 __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8) : 1) s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr,
                                                              int tr_lo, int a_lo, const int *__restrict__ a_tile_colidx,
@@ -416,8 +477,16 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
     __shared__ int s_cnt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
+#ifdef PEM_S1_DEBUG
+    constexpr int DBG_BIN = CAP == 512 ? 0 : CAP == 2048 ? 1 : CAP == 8192 ? 2 : 3;
+    unsigned long long dbg_t = 0;
+#endif
     for (int li = blockIdx.x; li < nrows_bin; li += gridDim.x) {
         const int i = row_list[li];
+#ifdef PEM_S1_DEBUG
+        if (tid == 0) dbg_t = wall_clock64();      // 100 MHz
+        const unsigned long long dbg_row0 = dbg_t;
+#endif
         if (tid == 0) s_cnt = 0;
         S1Row<KeyT, CAP, QB, THREADS, RCAP> row;
         row.keys = keys;
@@ -449,9 +518,11 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
             }
         }
         __syncthreads();
+        S1_DBG_MARK(0);
         // expand the row's products into (tile col, product index) keys -- live ones only -- and sort them; equal
         // tile columns stay in product (= ascending k) order because the index is part of the key
         const int nl = row.expand_compact(tid, &s_cnt, THREADS);
+        S1_DBG_MARK(1);
         if (nl <= THREADS)
             row.template sort_regs<1, LOGT>(tid);
         else if (nl <= THREADS * 2)
@@ -468,6 +539,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
             row.sort_lds(tid, nl);
         // stream out the live products (the dead ones sorted behind them): sorted pairs, and per distinct tile
         // column (C tile) its column + first pair; output positions count live products only
+        S1_DBG_MARK(2);
         const int lp0 = lprod_off[row.a0], nlive = nl;
         int base = 0;
         for (int s0 = 0; s0 < nlive; s0 += THREADS) {
@@ -480,7 +552,9 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
                 int q = (int)(key & KeyT((1u << QB) - 1u));
                 j = (int)(key >> QB);
                 head = s == 0 || (int)(keys[s - 1] >> QB) != j;
-                b = row.tile_b(q, &a);
+                const auto pr = row.tile_b(q, false);
+                a = pr.a;
+                b = pr.b;
             }
             unsigned long long bal = __ballot(head);
             if (lane == 0) wsum[wave] = __popcll(bal);
@@ -505,6 +579,22 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8
             __syncthreads();
         }
         if (tid == 0) row_tc[i] = base;
+        S1_DBG_MARK(3);
+#ifdef PEM_S1_DEBUG
+        if (tid == 0) {
+            if (blockIdx.x < 1024) {
+                unsigned hw, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                g_s1blk[DBG_BIN][blockIdx.x][0] = dbg_row0;
+                g_s1blk[DBG_BIN][blockIdx.x][1] = dbg_t;
+                g_s1blk[DBG_BIN][blockIdx.x][2] = hw;
+                g_s1blk[DBG_BIN][blockIdx.x][3] = xcc;
+            }
+            atomicAdd(&g_s1dbg[DBG_BIN][blockIdx.x & 1023][4], 1ull);
+            atomicMax(&g_s1dbg[DBG_BIN][blockIdx.x & 1023][5], dbg_t - dbg_row0);
+        }
+#endif
     }
 }
 
@@ -1139,7 +1229,6 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
     p->state = 0;
     p->pairs_ready = false;
     p->ntiles_c = p->npairs = p->nnz_c = 0;
-    PEM_TRY(zero_flags(ctx));
     PEM_HIP(hipEventRecord(ctx->ev[0], st));
     PEM_TRY(p->c_tile_rowptr.reserve(sizeof(int) * ((size_t)mt + 4)));
     PEM_HIP(hipMemsetAsync(p->c_tile_rowptr.p, 0, sizeof(int) * ((size_t)mt + 1), st));
@@ -1151,8 +1240,7 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
     if (nA > 0)
         PEM_LAUNCH(ctx, s1_aprod_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_colidx.as<int>(), A->tile_occ.as<uint32_t>(), p->a_lo, nA,
                    B->tile_rowptr.as<int>(), B->tile_occ.as<uint32_t>(), prune, p->aprod_off.as<int>(), p->lprod_off.as<int>());
-    PEM_TRY(exclusive_scan_i32(ctx, p->aprod_off.as<int>(), p->aprod_off.as<int>(), (size_t)nA, ctx->d_scalars + 3));
-    PEM_TRY(exclusive_scan_i32(ctx, p->lprod_off.as<int>(), p->lprod_off.as<int>(), (size_t)nA, ctx->d_scalars));
+    PEM_TRY(exclusive_scan_i32_pair(ctx, p->aprod_off.as<int>(), p->lprod_off.as<int>(), (size_t)nA, ctx->d_scalars + 3, ctx->d_scalars));
     int64_t P = 0, Pall = 0;
     {
         int64_t two[4];
@@ -1220,39 +1308,49 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
                          A->tile_occ.as<uint32_t>(), B->tile_occ.as<uint32_t>(), prune, p->pairs_a.as<int>(), p->pairs_b.as<int>(),   \
                          p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->c_tile_rowptr.as<int>());                             \
     }
-    // The bins are independent.  The largest is a handful of long-running single-CU blocks, and on small inputs
-    // every bin is tail-bound: fork bins 3, 2, 1 onto auxiliary streams next to bin 0 on the main stream so they
-    // fill each other's gaps; joined before the row-count scan.
+    // The bins are independent and run concurrently: the largest non-empty one on the main stream, the others
+    // forked onto auxiliary streams and joined before the row-count scan.  Order matters: a block of the 32768-key
+    // bin needs a CU's whole LDS, so it can only start on an EMPTY CU.  On the main stream it is dispatched the
+    // moment the row classification retires, a few microseconds before the forked streams get through their
+    // event waits, and its ~100 blocks are placed before the smaller bins flood the CUs (behind them it was
+    // starved until they drained, which made it the critical path of step 1).
     hipStream_t main_stream = ctx->stream;
     (void)hipEventRecord(ctx->ev_fork, main_stream);
     bool forked[3] = {false, false, false};
-    auto fork_begin = [&](int k) {
-        (void)hipStreamWaitEvent(ctx->aux[k], ctx->ev_fork, 0);
-        ctx->stream = ctx->aux[k];
-        forked[k] = true;
+    int next_aux = -1;                     // -1: the main stream is still free
+    auto bin_begin = [&]() {
+        if (next_aux < 0) return;
+        (void)hipStreamWaitEvent(ctx->aux[next_aux], ctx->ev_fork, 0);
+        ctx->stream = ctx->aux[next_aux];
+        forked[next_aux] = true;
     };
-    auto fork_end = [&](int k) {
-        (void)hipEventRecord(ctx->ev_join[k], ctx->aux[k]);
+    auto bin_end = [&]() {
+        if (next_aux >= 0) (void)hipEventRecord(ctx->ev_join[next_aux], ctx->aux[next_aux]);
         ctx->stream = main_stream;
+        ++next_aux;
     };
     if constexpr (sizeof(KeyT) == 4) {
         if (cap3 > S1_CAP2 && counts[3] > 0) {
-            fork_begin(0);
+            bin_begin();
             PEM_ROWSORT(3, 32768, QBITS, 1024, 2048, 1 << 20)
-            fork_end(0);
+            bin_end();
         }
     }
     if (counts[2] > 0) {
-        fork_begin(1);
+        bin_begin();
         PEM_ROWSORT(2, 8192, QBITS, 1024, 2048, 1 << 20)
-        fork_end(1);
+        bin_end();
     }
     if (counts[1] > 0) {
-        fork_begin(2);
+        bin_begin();
         PEM_ROWSORT(1, 2048, QBITS, 256, 1024, 1 << 20)
-        fork_end(2);
+        bin_end();
     }
-    PEM_ROWSORT(0, 512, QBITS, 64, 256, 1 << 20)
+    if (counts[0] > 0) {
+        bin_begin();
+        PEM_ROWSORT(0, 512, QBITS, 64, 256, 1 << 20)
+        bin_end();
+    }
 #undef PEM_ROWSORT
     for (int k = 0; k < 3; ++k)
         if (forked[k]) (void)hipStreamWaitEvent(main_stream, ctx->ev_join[k], 0);
@@ -1272,17 +1370,16 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     p->state = 0;
     p->pairs_ready = false;
     p->ntiles_c = p->npairs = p->nnz_c = 0;
-    PEM_TRY(zero_flags(ctx));
     PEM_HIP(hipEventRecord(ctx->ev[0], st));
     PEM_TRY(p->c_tile_rowptr.reserve(sizeof(int) * ((size_t)mt + 4)));
     PEM_TRY(p->row_list.reserve(sizeof(int) * (5 * (size_t)mt + 4)));
     PEM_TRY(p->bin_count.reserve(sizeof(int) * 8));
     PEM_TRY(p->xl_base.reserve(sizeof(int) * ((size_t)mt + 4)));
     PEM_TRY(p->pairs_offset.reserve(sizeof(int) * 4));
-    PEM_HIP(hipMemsetAsync(p->bin_count.p, 0, sizeof(int) * 8, st));
-    PEM_HIP(hipMemsetAsync(ctx->d_scalars, 0, sizeof(int64_t) * 4, st));   // P (live), T_C, C_nnz, P (all) of this pass
-    PEM_HIP(hipMemsetAsync(p->c_tile_rowptr.p, 0, sizeof(int) * ((size_t)mt + 1), st));
-    PEM_HIP(hipMemsetAsync(p->pairs_offset.p, 0, sizeof(int), st));
+    // one launch clears the status flags, the bin counters, the pass scalars (P live, T_C, C_nnz, P all) and
+    // pairs_offset[0]; the per-row tile counts in c_tile_rowptr are zeroed by the row classification below
+    PEM_LAUNCH(ctx, s1_reset_kernel, 1, 64, ctx->d_flags, p->bin_count.as<int>(), reinterpret_cast<long long *>(ctx->d_scalars),
+               p->pairs_offset.as<int>(), p->c_tile_rowptr.as<int>(), mt);
     // product offsets per A tile: all products (expansion / sort capacity) and live products (output positions)
     const char *prune_env = getenv("PEM_PRUNE");
     const int prune = !(prune_env && !strcmp(prune_env, "0"));
@@ -1291,8 +1388,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     if (nA > 0)
         PEM_LAUNCH(ctx, s1_aprod_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_colidx.as<int>(), A->tile_occ.as<uint32_t>(), p->a_lo, nA,
                    B->tile_rowptr.as<int>(), B->tile_occ.as<uint32_t>(), prune, p->aprod_off.as<int>(), p->lprod_off.as<int>());
-    PEM_TRY(exclusive_scan_i32(ctx, p->aprod_off.as<int>(), p->aprod_off.as<int>(), (size_t)nA, ctx->d_scalars + 3));
-    PEM_TRY(exclusive_scan_i32(ctx, p->lprod_off.as<int>(), p->lprod_off.as<int>(), (size_t)nA, ctx->d_scalars));
+    PEM_TRY(exclusive_scan_i32_pair(ctx, p->aprod_off.as<int>(), p->lprod_off.as<int>(), (size_t)nA, ctx->d_scalars + 3, ctx->d_scalars));
     // per-row tile counts are accumulated in c_tile_rowptr and scanned in place afterwards
     if (mt > 0)
         PEM_LAUNCH(ctx, s1_rowclass_kernel, grid_for((size_t)mt, 256), 256, A->tile_rowptr.as<int>(), p->tr_lo, mt, p->a_lo,
