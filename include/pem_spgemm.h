@@ -34,7 +34,9 @@ enum {
     PEM_E_OVERFLOW = -4,    /* a count does not fit the reference's int32 arrays */
     PEM_E_HIP = -5,         /* HIP runtime error */
     PEM_E_STATE = -6,       /* steps called out of order */
-    PEM_E_NODEVICE = -7     /* no usable GPU: the product path has no CPU fallback */
+    PEM_E_NODEVICE = -7,    /* no usable GPU: the product path has no CPU fallback */
+    PEM_E_IO = -8,          /* tiled-format cache: file missing, unreadable, truncated, corrupt or not a cache file */
+    PEM_E_STALE = -9        /* tiled-format cache: the file is intact but was made from a different source */
 };
 
 typedef struct pem_ctx pem_ctx;
@@ -91,6 +93,25 @@ typedef enum {
     PEM_T_TILE_OFFSETS       /* int32[T] CSC position -> CSR tile id             spgemm.cu:1034-1040 */
 } pem_tiled_array;
 pem_status pem_tiled_get_array(pem_ctx *ctx, const pem_tiled *t, pem_tiled_array which, void *host_dst, int64_t bytes);
+
+/* ---- on-disk cache of the tiled format -------------------------------------
+ * The reference parses the .mtx text and re-runs the whole conversion on every start, and its conversion clock
+ * includes the parse (spgemm.cu:760-1066).  A cache file holds the sorted tile payload of one tiling -- the tile
+ * list (spgemm.cu:869-877), perTileNnz (873-874), rowColIdx (195, 221) and vals (220) -- little-endian, with a
+ * checksum.  Loading uploads the four arrays, checks them ON THE DEVICE (sorted distinct in-range tiles, 1..256
+ * entries per tile, strictly ascending (r<<4|c) inside a tile, every entry inside rows x cols), then rebuilds the
+ * masks, intra-tile row pointers, transposed masks and the tile-level CSR/CSC indices with the conversion's own
+ * kernels: no parse, no sort.  A file that fails any check is rejected, never half-used.
+ * `key` identifies what the tiling was made from (the caller's choice, e.g. size + mtime of the .mtx and the
+ * transpose flag); load with a non-NULL `expect` returns PEM_E_STALE when the stored key differs. */
+typedef struct {
+    uint64_t source_size;      /* bytes of the source file                  */
+    int64_t source_mtime_ns;   /* its modification time                     */
+    uint32_t transpose;        /* the tiling is of the transposed source    */
+    uint32_t reserved;         /* 0                                         */
+} pem_cache_key;
+pem_status pem_tiled_save(pem_ctx *ctx, const pem_tiled *t, const char *path, const pem_cache_key *key);
+pem_status pem_tiled_load(pem_ctx *ctx, const char *path, const pem_cache_key *expect, pem_tiled **out);
 
 /* ---- a8: flop count (spgemm.cu:1068-1079), computed on the device ------------------------ */
 pem_status pem_flop_count(pem_ctx *ctx, const pem_tiled *A, const pem_tiled *B, uint64_t *flop);

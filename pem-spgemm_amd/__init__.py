@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libpemspgemm_hip.so")
 
 PEM_OK = 0
 STATUS_NAMES = {0: "PEM_OK", -1: "PEM_E_INVALID", -2: "PEM_E_DUPLICATE", -3: "PEM_E_NOMEM", -4: "PEM_E_OVERFLOW",
-                -5: "PEM_E_HIP", -6: "PEM_E_STATE", -7: "PEM_E_NODEVICE"}
+                -5: "PEM_E_HIP", -6: "PEM_E_STATE", -7: "PEM_E_NODEVICE", -8: "PEM_E_IO", -9: "PEM_E_STALE"}
 
 # enum pem_tiled_array / pem_cplan_array (include/pem_spgemm.h)
 T_ARRAYS = dict(tile_keys=(0, np.int64), tile_nnz_ptr=(1, np.int32), masks=(2, np.uint16), rowptr=(3, np.uint8),
@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "pem_tiled_get_array", "pem_flop_count", "pem_cplan_create", "pem_cplan_destroy", "pem_spgemm_step1", "pem_spgemm_step2",
     "pem_spgemm_step3", "pem_spgemm", "pem_cplan_get_info", "pem_cplan_get_array", "pem_c_export_csr", "pem_c_export_csr_device",
     "pem_c_export_coo", "pem_split_tile_rows", "pem_get_timings", "pem_set_kernel_profiling", "pem_reset_kernel_stats",
-    "pem_kernel_stats_count", "pem_kernel_stats_get",
+    "pem_kernel_stats_count", "pem_kernel_stats_get", "pem_tiled_save", "pem_tiled_load",
 ]
 
 
@@ -52,6 +52,16 @@ class TiledInfo(C.Structure):
 class CPlanInfo(C.Structure):
     _fields_ = [("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32), ("row_begin", C.c_int32), ("row_end", C.c_int32),
                 ("ntiles_c", C.c_int64), ("npairs", C.c_int64), ("nnz_c", C.c_int64), ("npairs_all", C.c_int64)]
+
+
+class CacheKey(C.Structure):
+    """pem_cache_key: what a cached tiling was made from (size + mtime of the source file, transpose flag)."""
+    _fields_ = [("source_size", C.c_uint64), ("source_mtime_ns", C.c_int64), ("transpose", C.c_uint32), ("reserved", C.c_uint32)]
+
+    @classmethod
+    def of_file(cls, path, transpose=False):
+        st = os.stat(path)
+        return cls(st.st_size, st.st_mtime_ns, int(bool(transpose)), 0)
 
 
 class Timings(C.Structure):
@@ -175,6 +185,17 @@ class Tiled:
         h = C.c_void_p()
         _check(lib().pem_tiled_from_csr(ctx._h, int(rows), int(cols), _p(rowptr, C.c_int32), _p(colidx, C.c_int32), _p(V, C.c_double),
                                         C.byref(h)))
+        return cls(ctx, h)
+
+    def save(self, path, key=None):
+        """Write the sorted tile payload to a cache file."""
+        _check(lib().pem_tiled_save(self.ctx._h, self._h, os.fsencode(path), C.byref(key) if key is not None else None))
+
+    @classmethod
+    def load(cls, ctx, path, expect=None):
+        """Rebuild a tiling from a cache file: upload, device-side validation, derived arrays -- no parse, no sort."""
+        h = C.c_void_p()
+        _check(lib().pem_tiled_load(ctx._h, os.fsencode(path), C.byref(expect) if expect is not None else None, C.byref(h)))
         return cls(ctx, h)
 
     def _count(self, name):

@@ -8,6 +8,12 @@
 // are bit-identical to the reference's (layouts in include/pem_spgemm.h).
 #include "pem_internal.h"
 #include <chrono>
+#include <cerrno>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unistd.h>
+#include <vector>
 
 using namespace pem;
 
@@ -368,6 +374,63 @@ extern "C" pem_status pem_kernel_stats_get(pem_ctx *ctx, int idx, char *name, in
 // ------------------------------------------------------------------------------------------
 // conversion driver
 // ------------------------------------------------------------------------------------------
+// Everything that follows from the sorted tile payload (tile_keys, tile_nnz_ptr, rowcolidx, vals): masks, intra-tile
+// row pointers, transposed masks (a5/a6), the step-3 records, the column-major values and the tile-level CSR/CSC
+// indices (a7).  Shared by the conversion and by the cache loader.  headx = exclusive scan of the tile-head flags;
+// ctx->ev[6] was recorded by the caller where its payload kernels start.
+static pem_status derive_tiled(pem_ctx *ctx, pem_tiled *T, const int *headx, int bits_tr, int bits_tc)
+{
+    const size_t nnz = (size_t)T->nnz, nt = (size_t)T->ntiles;
+    const int64_t ntiles = T->ntiles;
+    hipStream_t st = ctx->stream;
+    PEM_TRY(T->masks.reserve(sizeof(uint16_t) * 16 * (nt + 1)));
+    PEM_TRY(T->masks_t.reserve(sizeof(uint16_t) * 16 * (nt + 1)));
+    PEM_TRY(T->rowptr.reserve(16 * (nt + 1)));
+    PEM_TRY(T->tile_rec.reserve(sizeof(uint32_t) * 16 * (nt + 1)));
+    PEM_TRY(T->tile_occ.reserve(sizeof(uint32_t) * (nt + 4)));
+    PEM_TRY(T->tile_rec_t.reserve(sizeof(uint32_t) * 16 * (nt + 1)));
+    PEM_TRY(T->vals_t.reserve(sizeof(double) * (nnz + 1)));
+    PEM_TRY(T->tile_rowptr.reserve(sizeof(int) * ((size_t)T->tile_rows + 4)));
+    PEM_TRY(T->tile_colidx.reserve(sizeof(int) * (nt + 4)));
+    PEM_TRY(T->tile_colptr.reserve(sizeof(int) * ((size_t)T->tile_cols + 4)));
+    PEM_TRY(T->tile_rowidx.reserve(sizeof(int) * (nt + 4)));
+    PEM_TRY(T->tile_offsets.reserve(sizeof(int) * (nt + 4)));
+    PEM_HIP(hipMemsetAsync(T->tile_rowptr.p, 0, sizeof(int) * ((size_t)T->tile_rows + 1), st));
+    PEM_HIP(hipMemsetAsync(T->tile_colptr.p, 0, sizeof(int) * ((size_t)T->tile_cols + 1), st));
+    if (nnz) {
+        PEM_LAUNCH(ctx, conv_tile_meta_kernel, grid_for(nt * 16, 256), 256, T->rowcolidx.as<uint8_t>(), T->tile_nnz_ptr.as<int>(),
+                   (long long)ntiles, T->masks.as<uint16_t>(), T->rowptr.as<uint8_t>(), T->masks_t.as<uint16_t>(), T->tile_rec.as<uint32_t>(),
+                   T->tile_occ.as<uint32_t>(), T->tile_rec_t.as<uint32_t>());
+        PEM_LAUNCH(ctx, conv_vals_t_kernel, grid_for(nnz, 256), 256, T->rowcolidx.as<uint8_t>(), T->vals.as<double>(), headx, nnz,
+                   T->tile_nnz_ptr.as<int>(), T->tile_rec_t.as<uint32_t>(), T->vals_t.as<double>());
+    }
+    PEM_HIP(hipEventRecord(ctx->ev[7], st));
+    if (nt) {
+        PEM_LAUNCH(ctx, conv_tile_csr_kernel, grid_for(nt, 256), 256, T->tile_keys.as<long long>(), (long long)ntiles, T->tile_rows,
+                   T->tile_rowptr.as<int>(), T->tile_colidx.as<int>());
+        // column-major order of the tiles: second (small) radix sort, payload = CSR tile id
+        DevBuf &k0 = ctx->tmp[8], &k1 = ctx->tmp[9], &v0 = ctx->tmp[10], &v1 = ctx->tmp[11];   // context-owned, grow-only
+        PEM_TRY(k0.reserve(sizeof(uint64_t) * nt));
+        PEM_TRY(k1.reserve(sizeof(uint64_t) * nt));
+        PEM_TRY(v0.reserve(sizeof(uint32_t) * nt));
+        PEM_TRY(v1.reserve(sizeof(uint32_t) * nt));
+        PEM_LAUNCH(ctx, conv_csc_keys_kernel, grid_for(nt, 256), 256, T->tile_keys.as<long long>(), (long long)ntiles, bits_tr,
+                   k0.as<uint64_t>(), v0.as<uint32_t>());
+        uint64_t *ck = nullptr;
+        uint32_t *cp = nullptr;
+        PEM_TRY(radix_sort_u64_u32(ctx, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint32_t>(), v1.as<uint32_t>(), nt, bits_tr + bits_tc,
+                                   &ck, &cp));
+        PEM_LAUNCH(ctx, conv_tile_csc_kernel, grid_for(nt, 256), 256, ck, cp, (long long)ntiles, bits_tr, T->tile_cols,
+                   T->tile_colptr.as<int>(), T->tile_rowidx.as<int>(), T->tile_offsets.as<int>());
+    }
+    T->h_tile_rowptr.assign((size_t)T->tile_rows + 1, 0);
+    PEM_HIP(hipMemcpyAsync(T->h_tile_rowptr.data(), T->tile_rowptr.p, sizeof(int) * ((size_t)T->tile_rows + 1), hipMemcpyDeviceToHost, st));
+    PEM_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) T->conv_tile_kernel_ms = ms;
+    return PEM_OK;
+}
+
 // keys/perm already filled in k0/v0 (nnz entries); V = device values in input order.
 static pem_status build_tiled(pem_ctx *ctx, pem_tiled *T, DevBuf &k0, DevBuf &k1, DevBuf &v0, DevBuf &v1, const double *dV,
                               int bits_tr, int bits_tc)
@@ -401,56 +464,12 @@ static pem_status build_tiled(pem_ctx *ctx, pem_tiled *T, DevBuf &k0, DevBuf &k1
     PEM_TRY(T->tile_nnz_ptr.reserve(sizeof(int) * (nt + 4)));
     PEM_TRY(T->vals.reserve(sizeof(double) * (nnz + 1)));
     PEM_TRY(T->rowcolidx.reserve(nnz + 16));
-    PEM_TRY(T->masks.reserve(sizeof(uint16_t) * 16 * (nt + 1)));
-    PEM_TRY(T->masks_t.reserve(sizeof(uint16_t) * 16 * (nt + 1)));
-    PEM_TRY(T->rowptr.reserve(16 * (nt + 1)));
-    PEM_TRY(T->tile_rec.reserve(sizeof(uint32_t) * 16 * (nt + 1)));
-    PEM_TRY(T->tile_occ.reserve(sizeof(uint32_t) * (nt + 4)));
-    PEM_TRY(T->tile_rec_t.reserve(sizeof(uint32_t) * 16 * (nt + 1)));
-    PEM_TRY(T->vals_t.reserve(sizeof(double) * (nnz + 1)));
-    PEM_TRY(T->tile_rowptr.reserve(sizeof(int) * ((size_t)T->tile_rows + 4)));
-    PEM_TRY(T->tile_colidx.reserve(sizeof(int) * (nt + 4)));
-    PEM_TRY(T->tile_colptr.reserve(sizeof(int) * ((size_t)T->tile_cols + 4)));
-    PEM_TRY(T->tile_rowidx.reserve(sizeof(int) * (nt + 4)));
-    PEM_TRY(T->tile_offsets.reserve(sizeof(int) * (nt + 4)));
     PEM_HIP(hipMemsetAsync(T->tile_nnz_ptr.p, 0, sizeof(int) * (nt + 1), st));
-    PEM_HIP(hipMemsetAsync(T->tile_rowptr.p, 0, sizeof(int) * ((size_t)T->tile_rows + 1), st));
-    PEM_HIP(hipMemsetAsync(T->tile_colptr.p, 0, sizeof(int) * ((size_t)T->tile_cols + 1), st));
     PEM_HIP(hipEventRecord(ctx->ev[6], st));
-    if (nnz) {
+    if (nnz)
         PEM_LAUNCH(ctx, conv_fill_kernel, grid_for(nnz, 256), 256, keys, perm, head.as<int>(), nnz, dV, bits_tc, T->vals.as<double>(),
                    T->rowcolidx.as<uint8_t>(), T->tile_keys.as<long long>(), T->tile_nnz_ptr.as<int>());
-        PEM_LAUNCH(ctx, conv_tile_meta_kernel, grid_for(nt * 16, 256), 256, T->rowcolidx.as<uint8_t>(), T->tile_nnz_ptr.as<int>(),
-                   (long long)ntiles, T->masks.as<uint16_t>(), T->rowptr.as<uint8_t>(), T->masks_t.as<uint16_t>(), T->tile_rec.as<uint32_t>(),
-                   T->tile_occ.as<uint32_t>(), T->tile_rec_t.as<uint32_t>());
-    }
-    if (nnz)
-        PEM_LAUNCH(ctx, conv_vals_t_kernel, grid_for(nnz, 256), 256, T->rowcolidx.as<uint8_t>(), T->vals.as<double>(), head.as<int>(), nnz,
-                   T->tile_nnz_ptr.as<int>(), T->tile_rec_t.as<uint32_t>(), T->vals_t.as<double>());
-    PEM_HIP(hipEventRecord(ctx->ev[7], st));
-    if (nt) {
-        PEM_LAUNCH(ctx, conv_tile_csr_kernel, grid_for(nt, 256), 256, T->tile_keys.as<long long>(), (long long)ntiles, T->tile_rows,
-                   T->tile_rowptr.as<int>(), T->tile_colidx.as<int>());
-        // column-major order of the tiles: second (small) radix sort, payload = CSR tile id
-        PEM_TRY(k0.reserve(sizeof(uint64_t) * nt));
-        PEM_TRY(k1.reserve(sizeof(uint64_t) * nt));
-        PEM_TRY(v0.reserve(sizeof(uint32_t) * nt));
-        PEM_TRY(v1.reserve(sizeof(uint32_t) * nt));
-        PEM_LAUNCH(ctx, conv_csc_keys_kernel, grid_for(nt, 256), 256, T->tile_keys.as<long long>(), (long long)ntiles, bits_tr,
-                   k0.as<uint64_t>(), v0.as<uint32_t>());
-        uint64_t *ck = nullptr;
-        uint32_t *cp = nullptr;
-        PEM_TRY(radix_sort_u64_u32(ctx, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint32_t>(), v1.as<uint32_t>(), nt, bits_tr + bits_tc,
-                                   &ck, &cp));
-        PEM_LAUNCH(ctx, conv_tile_csc_kernel, grid_for(nt, 256), 256, ck, cp, (long long)ntiles, bits_tr, T->tile_cols,
-                   T->tile_colptr.as<int>(), T->tile_rowidx.as<int>(), T->tile_offsets.as<int>());
-    }
-    T->h_tile_rowptr.assign((size_t)T->tile_rows + 1, 0);
-    PEM_HIP(hipMemcpyAsync(T->h_tile_rowptr.data(), T->tile_rowptr.p, sizeof(int) * ((size_t)T->tile_rows + 1), hipMemcpyDeviceToHost, st));
-    PEM_HIP(hipStreamSynchronize(st));
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) T->conv_tile_kernel_ms = ms;
-    return PEM_OK;
+    return derive_tiled(ctx, T, head.as<int>(), bits_tr, bits_tc);
 }
 
 static pem_status tiled_from_device(pem_ctx *ctx, int rows, int cols, int64_t nnz, const int *dI, const int *dJ, const int *d_rowptr,
@@ -555,6 +574,276 @@ extern "C" pem_status pem_tiled_from_csr(pem_ctx *ctx, int rows, int cols, const
     pem_status s = tiled_from_device(ctx, rows, cols, nnz, nullptr, dJ.as<int>(), dR.as<int>(), dV.as<double>(), 0, out);
     (void)hipStreamSynchronize(ctx->stream);
     return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// on-disk cache of the tiled format (include/pem_spgemm.h documents the contract)
+// ------------------------------------------------------------------------------------------
+namespace {
+constexpr char CACHE_MAGIC[8] = {'P', 'E', 'M', 'T', 'I', 'L', 'E', '1'};
+struct CacheHeader {             // 128 bytes, little-endian, followed by the four arrays, each padded to 64 bytes
+    char magic[8];
+    uint32_t version;            // 1
+    uint32_t tile_size;          // 16
+    uint32_t value_bytes;        // 8 (fp64)
+    uint32_t header_bytes;       // 128
+    int32_t rows, cols;
+    int64_t nnz, ntiles;
+    pem_cache_key key;
+    uint64_t payload_bytes;      // everything after the header
+    uint64_t payload_hash;       // hash64 of the payload
+    uint64_t header_hash;        // hash64 of the header with this field zero
+    uint8_t pad[128 - 96];
+};
+static_assert(sizeof(CacheHeader) == 128, "cache header layout");
+
+inline size_t pad64(size_t n) { return (n + 63) & ~size_t(63); }
+
+// 64-bit multiply-rotate hash over 8-byte words (the tail is zero-padded), four interleaved lanes so the multiplies
+// pipeline (word i feeds lane i & 3); a corruption check, not a MAC.  Restated in tests/cachefmt.py.
+inline uint64_t hash_step(uint64_t h, uint64_t w)
+{
+    h = (h ^ w) * 0xD6E8FEB86659FD93ull;
+    return (h << 29) | (h >> 35);
+}
+uint64_t hash64(const void *data, size_t bytes, uint64_t seed)
+{
+    const unsigned char *p = static_cast<const unsigned char *>(data);
+    uint64_t h[4];
+    for (uint64_t k = 0; k < 4; ++k) h[k] = seed ^ (bytes * 0x9E3779B97F4A7C15ull) ^ (k * 0xA0761D6478BD642Full);
+    size_t i = 0;
+    for (; i + 32 <= bytes; i += 32) {
+        uint64_t w[4];
+        memcpy(w, p + i, 32);
+        h[0] = hash_step(h[0], w[0]);
+        h[1] = hash_step(h[1], w[1]);
+        h[2] = hash_step(h[2], w[2]);
+        h[3] = hash_step(h[3], w[3]);
+    }
+    for (int k = 0; i < bytes; i += 8, ++k) {
+        uint64_t w = 0;
+        memcpy(&w, p + i, bytes - i < 8 ? bytes - i : 8);
+        h[k] = hash_step(h[k], w);
+    }
+    uint64_t r = h[0];
+    for (int k = 1; k < 4; ++k) r = hash_step(r, h[k]);
+    r ^= r >> 32;
+    r *= 0xD6E8FEB86659FD93ull;
+    r ^= r >> 29;
+    return r;
+}
+
+struct CacheLayout {
+    size_t off_keys, off_ptr, off_rc, off_vals, total;
+};
+CacheLayout cache_layout(int64_t nnz, int64_t ntiles)
+{
+    CacheLayout L;
+    L.off_keys = 0;
+    L.off_ptr = L.off_keys + pad64(sizeof(long long) * (size_t)ntiles);
+    L.off_rc = L.off_ptr + pad64(sizeof(int) * ((size_t)ntiles + 1));
+    L.off_vals = L.off_rc + pad64((size_t)nnz);
+    L.total = L.off_vals + pad64(sizeof(double) * (size_t)nnz);
+    return L;
+}
+}   // namespace
+
+// One thread per tile: is the uploaded payload a valid tiled matrix?  Any violation raises FLAG_RANGE.  Offsets are
+// range-checked before they are used as indices, so a hostile file cannot steer a load out of bounds.
+__global__ void cache_check_kernel(const long long *__restrict__ tile_keys, const int *__restrict__ tile_nnz_ptr,
+                                   const uint8_t *__restrict__ rowcolidx, long long ntiles, long long nnz, int rows, int cols,
+                                   int tile_rows, int tile_cols, int *__restrict__ flags)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    bool ok = true;
+    const long long k = tile_keys[t];
+    const long long tr = k >> 32, tc = k & 0xFFFFFFFFll;
+    ok = ok && k >= 0 && tr < tile_rows && tc < tile_cols;
+    if (t > 0) ok = ok && tile_keys[t - 1] < k;                    // sorted, distinct (spgemm.cu:869-871)
+    const long long e0 = tile_nnz_ptr[t], e1 = tile_nnz_ptr[t + 1];
+    if (t == 0) ok = ok && e0 == 0;
+    if (t == ntiles - 1) ok = ok && e1 == nnz;
+    ok = ok && e0 >= 0 && e1 <= nnz && e1 > e0 && e1 - e0 <= 256;   // a listed tile holds 1..256 entries
+    if (ok) {
+        int prev = -1;
+        for (long long e = e0; e < e1; ++e) {
+            const int rc = rowcolidx[e];
+            ok = ok && rc > prev;                                   // row-major, no duplicates (spgemm.cu:195-222)
+            prev = rc;
+            ok = ok && tr * 16 + (rc >> 4) < rows && tc * 16 + (rc & 15) < cols;
+        }
+    }
+    if (!ok) flags[FLAG_RANGE] = 1;
+}
+
+__global__ void cache_heads_kernel(const int *__restrict__ tile_nnz_ptr, long long ntiles, int *__restrict__ head)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ntiles) head[tile_nnz_ptr[t]] = 1;
+}
+
+extern "C" pem_status pem_tiled_save(pem_ctx *ctx, const pem_tiled *T, const char *path, const pem_cache_key *key)
+{
+    if (!ctx || !T || !path || !*path) return PEM_E_INVALID;
+    PEM_HIP(hipSetDevice(ctx->device));
+    const CacheLayout L = cache_layout(T->nnz, T->ntiles);
+    std::vector<unsigned char> buf(sizeof(CacheHeader) + L.total, 0);
+    unsigned char *payload = buf.data() + sizeof(CacheHeader);
+    const size_t nt = (size_t)T->ntiles, nnz = (size_t)T->nnz;
+    hipStream_t st = ctx->stream;
+    if (nt) {
+        PEM_HIP(hipMemcpyAsync(payload + L.off_keys, T->tile_keys.p, sizeof(long long) * nt, hipMemcpyDeviceToHost, st));
+        PEM_HIP(hipMemcpyAsync(payload + L.off_ptr, T->tile_nnz_ptr.p, sizeof(int) * (nt + 1), hipMemcpyDeviceToHost, st));
+    }
+    if (nnz) {
+        PEM_HIP(hipMemcpyAsync(payload + L.off_rc, T->rowcolidx.p, nnz, hipMemcpyDeviceToHost, st));
+        PEM_HIP(hipMemcpyAsync(payload + L.off_vals, T->vals.p, sizeof(double) * nnz, hipMemcpyDeviceToHost, st));
+    }
+    PEM_HIP(hipStreamSynchronize(st));
+    CacheHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, CACHE_MAGIC, 8);
+    h.version = 1;
+    h.tile_size = 16;
+    h.value_bytes = 8;
+    h.header_bytes = sizeof(CacheHeader);
+    h.rows = T->rows;
+    h.cols = T->cols;
+    h.nnz = T->nnz;
+    h.ntiles = T->ntiles;
+    if (key) h.key = *key;
+    h.payload_bytes = L.total;
+    h.payload_hash = hash64(payload, L.total, 0x70656D74696C6531ull);
+    h.header_hash = 0;
+    h.header_hash = hash64(&h, sizeof h, 0x6865616465723031ull);
+    memcpy(buf.data(), &h, sizeof h);
+    // write next to the target, then rename: a reader never sees a half-written cache
+    const std::string tmp = std::string(path) + ".tmp." + std::to_string((long long)getpid());
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) {
+        set_error("pem_tiled_save: cannot create %s: %s", tmp.c_str(), strerror(errno));
+        return PEM_E_IO;
+    }
+    const bool wrote = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    const bool closed = fclose(f) == 0;
+    if (!wrote || !closed || rename(tmp.c_str(), path) != 0) {
+        set_error("pem_tiled_save: writing %s failed: %s", path, strerror(errno));
+        (void)remove(tmp.c_str());
+        return PEM_E_IO;
+    }
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_tiled_load(pem_ctx *ctx, const char *path, const pem_cache_key *expect, pem_tiled **out)
+{
+    if (!ctx || !path || !out) return PEM_E_INVALID;
+    *out = nullptr;
+    auto t0 = std::chrono::high_resolution_clock::now();
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        set_error("pem_tiled_load: cannot open %s: %s", path, strerror(errno));
+        return PEM_E_IO;
+    }
+    CacheHeader h;
+    auto fail = [&](const char *why) {
+        set_error("pem_tiled_load: %s: %s", path, why);
+        if (f) fclose(f);
+        f = nullptr;
+        return PEM_E_IO;
+    };
+    if (fread(&h, 1, sizeof h, f) != sizeof h) return fail("shorter than a cache header");
+    if (memcmp(h.magic, CACHE_MAGIC, 8) != 0) return fail("not a tiled-format cache file");
+    {
+        CacheHeader z = h;
+        z.header_hash = 0;
+        if (hash64(&z, sizeof z, 0x6865616465723031ull) != h.header_hash) return fail("header checksum mismatch");
+    }
+    if (h.version != 1 || h.tile_size != 16 || h.value_bytes != 8 || h.header_bytes != sizeof(CacheHeader))
+        return fail("unsupported cache version, tile size or value type");
+    if (h.rows <= 0 || h.cols <= 0 || h.nnz < 0 || h.nnz > 0x7FFFFFFFll || h.ntiles < 0 || h.ntiles > h.nnz ||
+        (h.nnz > 0 && h.ntiles == 0))
+        return fail("impossible dimensions in the header");
+    const CacheLayout L = cache_layout(h.nnz, h.ntiles);
+    if (h.payload_bytes != L.total) return fail("payload size does not match the dimensions");
+    if (expect && (expect->source_size != h.key.source_size || expect->source_mtime_ns != h.key.source_mtime_ns ||
+                   expect->transpose != h.key.transpose)) {
+        set_error("pem_tiled_load: %s was made from a different source (size %llu mtime %lld transpose %u)", path,
+                  (unsigned long long)h.key.source_size, (long long)h.key.source_mtime_ns, h.key.transpose);
+        fclose(f);
+        return PEM_E_STALE;
+    }
+    const bool trace = getenv("PEM_TRACE") != nullptr;
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[pem_tiled_load] %-18s %8.2f ms\n", what,
+                           std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count());
+    };
+    lap("header");
+    std::vector<unsigned char> payload(L.total + 8);
+    lap("buffer");
+    if (fread(payload.data(), 1, L.total, f) != L.total) return fail("truncated payload");
+    lap("read");
+    if (fgetc(f) != EOF) return fail("trailing bytes after the payload");
+    fclose(f);
+    f = nullptr;
+    if (hash64(payload.data(), L.total, 0x70656D74696C6531ull) != h.payload_hash) return fail("payload checksum mismatch");
+    lap("checksum");
+
+    PEM_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    pem_tiled *T = new pem_tiled();
+    T->rows = h.rows;
+    T->cols = h.cols;
+    T->nnz = h.nnz;
+    T->ntiles = h.ntiles;
+    T->tile_rows = (T->rows + 15) / 16;
+    T->tile_cols = (T->cols + 15) / 16;
+    const int bits_tr = bits_for((uint64_t)T->tile_rows), bits_tc = bits_for((uint64_t)T->tile_cols);
+    const size_t nt = (size_t)h.ntiles, nnz = (size_t)h.nnz;
+    auto body = [&]() -> pem_status {
+        PEM_TRY(zero_flags(ctx));
+        PEM_TRY(T->tile_keys.reserve(sizeof(long long) * (nt + 1)));
+        PEM_TRY(T->tile_nnz_ptr.reserve(sizeof(int) * (nt + 4)));
+        PEM_TRY(T->vals.reserve(sizeof(double) * (nnz + 1)));
+        PEM_TRY(T->rowcolidx.reserve(nnz + 16));
+        DevBuf &head = ctx->tmp[0];
+        PEM_TRY(head.reserve(sizeof(int) * (nnz + 4)));
+        PEM_HIP(hipMemsetAsync(T->tile_nnz_ptr.p, 0, sizeof(int) * (nt + 1), st));
+        if (nt) {
+            PEM_HIP(hipMemcpyAsync(T->tile_keys.p, payload.data() + L.off_keys, sizeof(long long) * nt, hipMemcpyHostToDevice, st));
+            PEM_HIP(hipMemcpyAsync(T->tile_nnz_ptr.p, payload.data() + L.off_ptr, sizeof(int) * (nt + 1), hipMemcpyHostToDevice, st));
+        }
+        if (nnz) {
+            PEM_HIP(hipMemcpyAsync(T->rowcolidx.p, payload.data() + L.off_rc, nnz, hipMemcpyHostToDevice, st));
+            PEM_HIP(hipMemcpyAsync(T->vals.p, payload.data() + L.off_vals, sizeof(double) * nnz, hipMemcpyHostToDevice, st));
+        }
+        PEM_HIP(hipEventRecord(ctx->ev[6], st));
+        lap("alloc + upload");
+        if (nt)
+            PEM_LAUNCH(ctx, cache_check_kernel, grid_for(nt, 256), 256, T->tile_keys.as<long long>(), T->tile_nnz_ptr.as<int>(),
+                       T->rowcolidx.as<uint8_t>(), (long long)nt, (long long)nnz, T->rows, T->cols, T->tile_rows, T->tile_cols, ctx->d_flags);
+        int hf[NUM_FLAGS];
+        PEM_TRY(read_flags(ctx, hf));   // before anything indexes through the file's offsets
+        if (hf[FLAG_RANGE]) {
+            set_error("pem_tiled_load: %s: the payload is not a valid tiled matrix (checksum intact: written by a faulty producer)", path);
+            return PEM_E_IO;
+        }
+        PEM_HIP(hipMemsetAsync(head.p, 0, sizeof(int) * (nnz + 1), st));
+        if (nt) PEM_LAUNCH(ctx, cache_heads_kernel, grid_for(nt, 256), 256, T->tile_nnz_ptr.as<int>(), (long long)nt, head.as<int>());
+        PEM_TRY(exclusive_scan_i32(ctx, head.as<int>(), head.as<int>(), nnz, nullptr));
+        lap("check");
+        return derive_tiled(ctx, T, head.as<int>(), bits_tr, bits_tc);
+    };
+    pem_status s = body();
+    (void)hipStreamSynchronize(st);
+    lap("derive");
+    if (s != PEM_OK) {
+        delete T;
+        return s;
+    }
+    T->conv_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    *out = T;
+    return PEM_OK;
 }
 
 extern "C" pem_status pem_tiled_destroy(pem_ctx *ctx, pem_tiled *t)

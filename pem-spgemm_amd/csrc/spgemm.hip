@@ -457,7 +457,7 @@ extern "C" void pem_debug_s1(unsigned long long *out32, int reset)
 #endif
 
 template <typename KeyT, int CAP, int QB, int THREADS, int RCAP>
-__global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 ? 4 : 8) : 1) s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr,
+__global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || sizeof(KeyT) == 8 ? 4 : 8) : 1) s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr,
                                                              int tr_lo, int a_lo, const int *__restrict__ a_tile_colidx,
                                                              const int *__restrict__ aprod_off, const int *__restrict__ lprod_off,
                                                              const int *__restrict__ b_tile_rowptr, const int *__restrict__ b_tile_colidx,

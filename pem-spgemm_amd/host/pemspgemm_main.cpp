@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <sys/stat.h>
 #include <vector>
 #include "../../include/pem_host.h"
 #include "../../include/pem_spgemm.h"
@@ -34,12 +35,15 @@ int main(int argc, char *argv[])
 {
     // Beyond the reference: `--B <file.mtx>` multiplies by a second matrix instead of A itself,
     // `--out <file.mtx>` writes C as a Matrix-Market file.  They are stripped before the reference's own grammar.
-    const char *b_path = nullptr, *out_path = nullptr;
+    // `--cache <dir>` keeps each tiling as <dir>/<stem>.<A|AT>.pemtile and, while the .mtx is unchanged
+    // (size + mtime), loads it instead of parsing and converting.
+    const char *b_path = nullptr, *out_path = nullptr, *cache_dir = nullptr;
     {
         int w = 1;
         for (int r = 1; r < argc; ++r) {
             if (!strcmp(argv[r], "--B") && r + 1 < argc) b_path = argv[++r];
             else if (!strcmp(argv[r], "--out") && r + 1 < argc) out_path = argv[++r];
+            else if (!strcmp(argv[r], "--cache") && r + 1 < argc) cache_dir = argv[++r];
             else argv[w++] = argv[r];
         }
         argc = w;
@@ -54,49 +58,87 @@ int main(int argc, char *argv[])
     const bool save = argc >= 3 && atoi(argv[2]) != 0;     // spgemm.cu:1485 (the reference dereferences argv[2] unconditionally)
     const bool aat = argc == 4;                            // spgemm.cu:788: presence of a 3rd argument, value ignored
 
-    auto conv_start = std::chrono::high_resolution_clock::now();   // spgemm.cu:760: the clock starts before the file is read
-    pem_coo m;
-    if (pem_mm_read(argv[1], 0, &m) != 0) {
-        fprintf(stderr, "pemspgemm: %s\n", pem_host_last_error());
-        return 1;
-    }
-    pem_coo mb;
-    memset(&mb, 0, sizeof mb);
-    if (b_path) {
-        if (pem_mm_read(b_path, 0, &mb) != 0) {
-            fprintf(stderr, "pemspgemm: %s\n", pem_host_last_error());
-            return 1;
-        }
-        const int brows = aat ? mb.cols : mb.rows;
-        if (m.cols != brows) {
-            printf("inner dimensions differ: A is %d x %d, B%s is %d x %d. Exiting.\n", m.rows, m.cols, aat ? "^T" : "", brows,
-                   aat ? mb.rows : mb.cols);
-            return 1;
-        }
-    }
-    if (!b_path && m.rows != m.cols && !aat) {   // spgemm.cu:782-786
-        printf("input is rectangular. Only AAt is possible. Exiting.\n");
-        return 1;
-    }
-    const pem_coo &bsrc = b_path ? mb : m;
-    const int b_rows = aat ? bsrc.cols : bsrc.rows, b_cols = aat ? bsrc.rows : bsrc.cols;
-    printf("MATRIX A\nfilepath: %s\nRows: %d\nCols: %d\nNnz: %lld\n", argv[1], m.rows, m.cols, (long long)m.nnz);   // spgemm.cu:794-806
-    printf("MATRIX B\nfilepath: %s\nRows: %d\nCols: %d\nNnz: %lld\n", b_path ? b_path : argv[1], b_rows, b_cols, (long long)bsrc.nnz);
-
-    pem_ctx *ctx = nullptr;
+    pem_ctx *ctx = nullptr;   // device + memory set-up precede the conversion clock, as in the reference (spgemm.cu:730-758)
     CHECK(pem_ctx_create(env_int("PEM_DEVICE", 0), &ctx));
+    auto conv_start = std::chrono::high_resolution_clock::now();   // spgemm.cu:760: the clock starts before the file is read
+    // One tiling = (source file, transposed?).  With --cache it is loaded from <dir>/<stem>.<A|AT>.pemtile when that
+    // file was made from the same .mtx (size + mtime), else parsed + converted and then saved there.
+    struct Source {
+        const char *path;
+        pem_coo coo;
+        bool read = false;
+    };
+    Source srcA = {argv[1], {}, false}, srcB = {b_path, {}, false};
+    memset(&srcA.coo, 0, sizeof srcA.coo);
+    memset(&srcB.coo, 0, sizeof srcB.coo);
+    int cache_hits = 0, cache_misses = 0;
+    auto make_tiling = [&](Source &src, int transpose, pem_tiled **out) -> int {
+        std::string cpath;
+        pem_cache_key key;
+        memset(&key, 0, sizeof key);
+        bool keyed = false;
+        if (cache_dir) {
+            struct stat st;
+            if (stat(src.path, &st) == 0) {
+                key.source_size = (uint64_t)st.st_size;
+                key.source_mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+                key.transpose = (uint32_t)transpose;
+                keyed = true;
+                std::string p = src.path;
+                size_t sl = p.find_last_of('/');
+                std::string stem = sl == std::string::npos ? p : p.substr(sl + 1);
+                cpath = std::string(cache_dir) + "/" + stem + (transpose ? ".AT" : ".A") + ".pemtile";
+                pem_status ls = pem_tiled_load(ctx, cpath.c_str(), &key, out);
+                if (ls == PEM_OK) {
+                    ++cache_hits;
+                    return 0;
+                }
+                if (ls != PEM_E_IO && ls != PEM_E_STALE) {
+                    fprintf(stderr, "pemspgemm: %s\n", pem_last_error());
+                    return 2;
+                }
+                ++cache_misses;   // absent, stale or damaged: rebuild below and overwrite
+            }
+        }
+        if (!src.read) {
+            if (pem_mm_read(src.path, 0, &src.coo) != 0) {
+                fprintf(stderr, "pemspgemm: %s\n", pem_host_last_error());
+                return 1;
+            }
+            src.read = true;
+        }
+        const pem_coo &m = src.coo;
+        if (pem_tiled_from_coo(ctx, m.rows, m.cols, m.nnz, m.I, m.J, m.V, transpose, out) != PEM_OK) {
+            fprintf(stderr, "pemspgemm: conversion of %s failed: %s\n", src.path, pem_last_error());
+            return 2;
+        }
+        if (keyed && pem_tiled_save(ctx, *out, cpath.c_str(), &key) != PEM_OK)
+            fprintf(stderr, "pemspgemm: cache not written: %s\n", pem_last_error());   // not fatal
+        return 0;
+    };
     pem_tiled *A = nullptr, *B = nullptr;
-    CHECK(pem_tiled_from_coo(ctx, m.rows, m.cols, m.nnz, m.I, m.J, m.V, 0, &A));
-    if (b_path)
-        CHECK(pem_tiled_from_coo(ctx, mb.rows, mb.cols, mb.nnz, mb.I, mb.J, mb.V, aat ? 1 : 0, &B));
-    else if (aat)
-        CHECK(pem_tiled_from_coo(ctx, m.rows, m.cols, m.nnz, m.I, m.J, m.V, 1, &B));
-    else
+    if (int rc = make_tiling(srcA, 0, &A)) return rc;
+    if (b_path) {
+        if (int rc = make_tiling(srcB, aat ? 1 : 0, &B)) return rc;
+    } else if (aat) {
+        if (int rc = make_tiling(srcA, 1, &B)) return rc;
+    } else {
         B = A;   // the reference converts the same file twice (spgemm.cu:778-779); one tiling serves both roles here
-    const double conv_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - conv_start).count();
+    }
     pem_tiled_info ia, ib;
     CHECK(pem_tiled_get_info(A, &ia));
     CHECK(pem_tiled_get_info(B, &ib));
+    if (ia.cols != ib.rows) {
+        if (b_path)
+            printf("inner dimensions differ: A is %d x %d, B%s is %d x %d. Exiting.\n", ia.rows, ia.cols, aat ? "^T" : "", ib.rows, ib.cols);
+        else
+            printf("input is rectangular. Only AAt is possible. Exiting.\n");   // spgemm.cu:782-786
+        return 1;
+    }
+    printf("MATRIX A\nfilepath: %s\nRows: %d\nCols: %d\nNnz: %lld\n", argv[1], ia.rows, ia.cols, (long long)ia.nnz);   // spgemm.cu:794-806
+    printf("MATRIX B\nfilepath: %s\nRows: %d\nCols: %d\nNnz: %lld\n", b_path ? b_path : argv[1], ib.rows, ib.cols, (long long)ib.nnz);
+    if (cache_dir) printf("tiled-format cache %s: %d loaded, %d rebuilt\n", cache_dir, cache_hits, cache_misses);
+    const double conv_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - conv_start).count();
     uint64_t flop = 0;
     CHECK(pem_flop_count(ctx, A, B, &flop));   // spgemm.cu:1068-1079
 
@@ -201,7 +243,7 @@ int main(int argc, char *argv[])
     if (B != A) pem_tiled_destroy(ctx, B);
     pem_tiled_destroy(ctx, A);
     pem_ctx_destroy(ctx);
-    pem_coo_free(&m);
-    pem_coo_free(&mb);
+    pem_coo_free(&srcA.coo);
+    pem_coo_free(&srcB.coo);
     return rc;
 }

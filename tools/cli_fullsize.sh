@@ -24,4 +24,13 @@ rm -f pemspgemm_benchmark_result.csv
 for m in scircuit webbase-1M; do ../../pem-spgemm_amd/pemspgemm $PWD/$m.mtx 0 > $m.log 2>&1; tail -22 $m.log | head -18; done
 ../../pem-spgemm_amd/pemspgemm $PWD/mc2depi.mtx 0 1 > mc2depi.log 2>&1; tail -22 mc2depi.log | head -18
 cat pemspgemm_benchmark_result.csv; echo
-rm -f *.mtx
+# tiled-format cache: cold run parses + converts + writes, warm run loads
+mkdir -p cache
+for m in scircuit webbase-1M; do
+    for pass in cold warm; do
+        PEM_CSV=cache.csv ../../pem-spgemm_amd/pemspgemm $PWD/$m.mtx 0 --cache $PWD/cache > cache_$m.$pass.log 2>&1
+        echo "$m --cache $pass: $(grep -E 'tiled-format cache|total conversion overhead' cache_$m.$pass.log | tr '\n' ' ')"
+    done
+done
+ls -l cache | awk '{print $5, $9}'
+rm -rf cache *.mtx
