@@ -90,6 +90,7 @@ struct pem_ctx {
     // shared temporaries (grow-only, reused by every call on this context)
     pem::DevBuf scan_bsum;             // block sums of the device scan
     pem::DevBuf sort_hist;             // radix-sort histograms
+    bool chain_events = false;         // pem_spgemm: steps run back to back, boundary events are shared
     pem::DevBuf tmp[12];               // step/convert temporaries, see call sites
     // timing
     hipEvent_t ev[8] = {};             // step spans

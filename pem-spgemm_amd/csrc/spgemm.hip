@@ -258,12 +258,15 @@ __device__ __forceinline__ void s1_bitonic_regs(KeyT (&v)[EPT], KeyT *lds, const
             } else if (lj < LOGE + 6) {  // partner in another lane of this wave
                 const int lm = jj >> LOGE;
                 const bool lower = (tid & lm) == 0;
+                // all EPT exchanges are issued before the first result is used: written as one loop the compiler
+                // emitted ds_bpermute / s_waitcnt lgkmcnt(0) pairs, i.e. one full LDS latency per key and stage
+                KeyT pv[EPT];
 #pragma unroll
-                for (int m = 0; m < EPT; ++m) {
-                    const KeyT pv = s1_shfl_xor<KeyT>(v[m], lm);
+                for (int m = 0; m < EPT; ++m) pv[m] = s1_shfl_xor<KeyT>(v[m], lm);
+#pragma unroll
+                for (int m = 0; m < EPT; ++m) {   // compare + select (the lane predicate folds into the mask on the scalar unit)
                     const bool up = (((tid << LOGE) | m) & kk) == 0;
-                    const KeyT mn = v[m] < pv ? v[m] : pv, mx = v[m] < pv ? pv : v[m];
-                    v[m] = (lower == up) ? mn : mx;
+                    v[m] = ((v[m] < pv[m]) == (lower == up)) ? v[m] : pv[m];
                 }
             } else {                     // partner in another wave: through LDS ([m][tid] image: conflict-free)
                 const int tm = jj >> LOGE;
@@ -275,8 +278,7 @@ __device__ __forceinline__ void s1_bitonic_regs(KeyT (&v)[EPT], KeyT *lds, const
                 for (int m = 0; m < EPT; ++m) {
                     const KeyT pv = lds[m * THREADS + (tid ^ tm)];
                     const bool up = (((tid << LOGE) | m) & kk) == 0;
-                    const KeyT mn = v[m] < pv ? v[m] : pv, mx = v[m] < pv ? pv : v[m];
-                    v[m] = (lower == up) ? mn : mx;
+                    v[m] = ((v[m] < pv) == (lower == up)) ? v[m] : pv;
                 }
                 __syncthreads();
             }
@@ -385,27 +387,87 @@ struct S1Row {
             }
         }
     }
-    // THREADS*16 < live keys <= THREADS*32: sort each half in registers (second half written back descending),
-    // which leaves one bitonic sequence; 15 merge stages in LDS finish it (a plain LDS bitonic sort needs 120)
-    template <int LOGT> __device__ __forceinline__ void sort_halves(const int tid) const
+    // lanes of the wave holding the same 8-bit digit as this one (among the valid lanes)
+    static __device__ __forceinline__ unsigned long long match_digit(const bool valid, const unsigned d)
     {
-        constexpr int HALF = THREADS * 16;
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {     // one copy of the sort code: two would double the register pressure
-            KeyT *half = keys + h * HALF;
-            KeyT v[16];
+        unsigned long long m = __ballot(valid);
 #pragma unroll
-            for (int m = 0; m < 16; ++m) v[m] = half[m * THREADS + tid];
-            __syncthreads();
-            s1_bitonic_regs<KeyT, THREADS, 16, LOGT>(v, half, tid, h == 1);
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
         }
-        for (int jj = HALF; jj > 0; jj >>= 1) {
-            for (int t = tid; t < HALF; t += THREADS) {
-                const int lo = 2 * t - (t & (jj - 1)), hi = lo + jj;
-                const KeyT x = keys[lo], y = keys[hi];
-                if (x > y) {
-                    keys[lo] = y;
-                    keys[hi] = x;
+        return m;
+    }
+    template <int EPT> __device__ __forceinline__ void sort_radix(const int tid, const int n, unsigned *hist, int *wsum, const int key_bits) const
+    {
+        static_assert(THREADS == 1024, "sized for 16 waves: 4096 counters, four per thread in the scan");
+        constexpr int WAVES = THREADS / 64;
+        const int lane = tid & 63, wave = tid >> 6;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const int rpw = (n + THREADS - 1) / THREADS;   // rounds per wave, <= EPT
+        const int e0 = wave * rpw * 64 + lane;
+        unsigned *myhist = hist + wave * 256;
+        for (int shift = 0; shift < key_bits; shift += 8) {
+            KeyT k[EPT];
+#pragma unroll
+            for (int r = 0; r < EPT; ++r) k[r] = (r < rpw && e0 + r * 64 < n) ? keys[e0 + r * 64] : KeyT(0);
+            for (int x = tid; x < WAVES * 256; x += THREADS) hist[x] = 0;
+            __syncthreads();
+            // digit counts: one LDS atomic per key, except where the whole round holds one digit (the product-index
+            // bits of neighbouring products, already grouped columns) -- 64 atomics on one counter serialise, so
+            // there the first lane adds the round's population instead
+#pragma unroll
+            for (int r = 0; r < EPT; ++r) {
+                if (r >= rpw) break;                       // wave-uniform
+                const bool valid = e0 + r * 64 < n;
+                const unsigned long long vm = __ballot(valid);
+                if (vm == 0) break;
+                const unsigned d = (unsigned)(k[r] >> shift) & 255u;
+                const unsigned d0 = (unsigned)__shfl((int)d, __builtin_ctzll(vm), 64);
+                if (__ballot(valid && d != d0) == 0) {
+                    if (lane == 0) myhist[d0] += (unsigned)__popcll(vm);
+                } else if (valid) {
+                    atomicAdd(&myhist[d], 1u);
+                }
+            }
+            __syncthreads();
+            {   // exclusive scan over (digit, wave): thread t owns digit t>>2, waves 4(t&3) .. 4(t&3)+3
+                const int d = tid >> 2, w0 = (tid & 3) * 4;
+                unsigned v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = hist[(w0 + j) * 256 + d];
+                const int tsum = (int)(v[0] + v[1] + v[2] + v[3]);
+                int inc = tsum;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    const int o = __shfl_up(inc, dd, 64);
+                    if (lane >= dd) inc += o;
+                }
+                if (lane == 63) wsum[wave] = inc;
+                __syncthreads();
+                int ex = inc - tsum;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w)
+                    if (w < wave) ex += wsum[w];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    hist[(w0 + j) * 256 + d] = (unsigned)ex;
+                    ex += (int)v[j];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < EPT; ++r) {
+                if (r >= rpw) break;                       // wave-uniform
+                const bool valid = e0 + r * 64 < n;
+                const unsigned d = (unsigned)(k[r] >> shift) & 255u;
+                const unsigned long long m = match_digit(valid, d);
+                if (valid) {
+                    const unsigned base = myhist[d];
+                    const int rank = __popcll(m & lt);
+                    keys[base + rank] = k[r];
+                    if (rank == 0) myhist[d] = base + (unsigned)__popcll(m);
                 }
             }
             __syncthreads();
@@ -464,7 +526,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
                                                              const uint32_t *__restrict__ a_occ, const uint32_t *__restrict__ b_occ, int prune,
                                                              int *__restrict__ pairs_a, int *__restrict__ pairs_b,
                                                              int *__restrict__ scratch_col, int *__restrict__ scratch_off,
-                                                             int *__restrict__ row_tc)
+                                                             int *__restrict__ row_tc, int key_bits)
 {
     constexpr int LOGT = THREADS == 64 ? 6 : THREADS == 256 ? 8 : 10;
     constexpr int EMAX = CAP / THREADS;
@@ -475,6 +537,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
     __shared__ unsigned rco[RCAP];     // occupied columns of that A tile
     __shared__ int wsum[THREADS / 64];
     __shared__ int s_cnt;
+    __shared__ unsigned radix_hist[CAP > 8192 ? (THREADS / 64) * 256 : 1];   // digit counters of the radix sort (largest bin)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
 #ifdef PEM_S1_DEBUG
@@ -531,10 +594,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
             row.template sort_regs<4, LOGT>(tid);
         else if (nl <= THREADS * 8)
             row.template sort_regs<8, LOGT>(tid);
-        else if (EMAX > 8 && nl <= THREADS * 16)
-            row.template sort_regs<(EMAX > 8 ? 16 : 8), LOGT>(tid);
-        else if (EMAX == 32 && CAP == THREADS * 32)
-            row.template sort_halves<LOGT>(tid);      // keys are padded to CAP by expand_compact
+        else if constexpr (EMAX == 32 && THREADS == 1024)
+            row.template sort_radix<32>(tid, nl, radix_hist, wsum, key_bits);
         else
             row.sort_lds(tid, nl);
         // stream out the live products (the dead ones sorted behind them): sorted pairs, and per distinct tile
@@ -1212,10 +1273,10 @@ extern "C" pem_status pem_cplan_get_info(const pem_cplan *p, pem_cplan_info *inf
     return PEM_OK;
 }
 
-static pem_status step_elapsed(pem_ctx *ctx, int e0, double *dst)
+static pem_status step_elapsed(pem_ctx *ctx, int e0, int e1, double *dst)
 {
     float ms = 0.f;
-    PEM_HIP(hipEventElapsedTime(&ms, ctx->ev[e0], ctx->ev[e0 + 1]));
+    PEM_HIP(hipEventElapsedTime(&ms, ctx->ev[e0], ctx->ev[e1]));
     *dst = ms;
     return PEM_OK;
 }
@@ -1299,6 +1360,7 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
     const pem_tiled *A = p->A, *B = p->B;
     int *rl = p->row_list.as<int>();
     constexpr int QBITS = sizeof(KeyT) == 4 ? 15 : 24;   // product-index field of the sort key
+    const int key_bits = QBITS + bits_for((uint64_t)B->tile_cols);
 #define PEM_ROWSORT(BIN, CAP, QB, THREADS, RCAP, MAXGRID)                                                                                 \
     if (counts[BIN] > 0) {                                                                                                           \
         int grid = counts[BIN] < (MAXGRID) ? counts[BIN] : (MAXGRID);                                                                \
@@ -1306,7 +1368,7 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
                          rl + (size_t)(BIN) * mt, counts[BIN], A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, A->tile_colidx.as<int>(), \
                          p->aprod_off.as<int>(), p->lprod_off.as<int>(), B->tile_rowptr.as<int>(), B->tile_colidx.as<int>(),         \
                          A->tile_occ.as<uint32_t>(), B->tile_occ.as<uint32_t>(), prune, p->pairs_a.as<int>(), p->pairs_b.as<int>(),   \
-                         p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->c_tile_rowptr.as<int>());                             \
+                         p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->c_tile_rowptr.as<int>(), key_bits);                   \
     }
     // The bins are independent and run concurrently: the largest non-empty one on the main stream, the others
     // forked onto auxiliary streams and joined before the row-count scan.  Order matters: a block of the 32768-key
@@ -1332,7 +1394,7 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
     if constexpr (sizeof(KeyT) == 4) {
         if (cap3 > S1_CAP2 && counts[3] > 0) {
             bin_begin();
-            PEM_ROWSORT(3, 32768, QBITS, 1024, 2048, 1 << 20)
+            PEM_ROWSORT(3, 32768, QBITS, 1024, 1024, 1 << 20)
             bin_end();
         }
     }
@@ -1504,7 +1566,7 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
     const pem_tiled *A = p->A, *B = p->B;
     hipStream_t st = ctx->stream;
     const size_t n = (size_t)p->npairs, ntc = (size_t)p->ntiles_c;
-    PEM_HIP(hipEventRecord(ctx->ev[2], st));
+    if (!ctx->chain_events) PEM_HIP(hipEventRecord(ctx->ev[2], st));   // inside pem_spgemm the previous step's end event is the start
     PEM_TRY(p->pairs_a.reserve(sizeof(int) * (n + 4)));
     PEM_TRY(p->pairs_b.reserve(sizeof(int) * (n + 4)));
     PEM_TRY(p->c_mask.reserve(sizeof(uint32_t) * 8 * (ntc + 1)));
@@ -1561,7 +1623,7 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
     const pem_tiled *A = p->A, *B = p->B;
     hipStream_t st = ctx->stream;
     const size_t ntc = (size_t)p->ntiles_c;
-    PEM_HIP(hipEventRecord(ctx->ev[4], st));
+    if (!ctx->chain_events) PEM_HIP(hipEventRecord(ctx->ev[4], st));
     const char *wide_env = getenv("PEM_WIDE");
     const bool wide = !(wide_env && !strcmp(wide_env, "0"));
     if (ntc > 0 && wide)
@@ -1585,7 +1647,7 @@ extern "C" pem_status pem_spgemm_step1(pem_ctx *ctx, pem_cplan *plan)
     PEM_HIP(hipSetDevice(ctx->device));
     PEM_TRY(step1_impl(ctx, plan, false));   // step-wise calls always read the sizes back
     PEM_HIP(hipStreamSynchronize(ctx->stream));
-    return step_elapsed(ctx, 0, &ctx->timings.step1_ms);
+    return step_elapsed(ctx, 0, 1, &ctx->timings.step1_ms);
 }
 
 extern "C" pem_status pem_spgemm_step2(pem_ctx *ctx, pem_cplan *plan)
@@ -1594,7 +1656,7 @@ extern "C" pem_status pem_spgemm_step2(pem_ctx *ctx, pem_cplan *plan)
     PEM_HIP(hipSetDevice(ctx->device));
     PEM_TRY(step2_impl(ctx, plan));
     PEM_HIP(hipStreamSynchronize(ctx->stream));
-    return step_elapsed(ctx, 2, &ctx->timings.step2_ms);
+    return step_elapsed(ctx, 2, 3, &ctx->timings.step2_ms);
 }
 
 extern "C" pem_status pem_spgemm_step3(pem_ctx *ctx, pem_cplan *plan)
@@ -1603,7 +1665,7 @@ extern "C" pem_status pem_spgemm_step3(pem_ctx *ctx, pem_cplan *plan)
     PEM_HIP(hipSetDevice(ctx->device));
     PEM_TRY(step3_impl(ctx, plan));
     PEM_HIP(hipStreamSynchronize(ctx->stream));
-    return step_elapsed(ctx, 4, &ctx->timings.step3_ms);
+    return step_elapsed(ctx, 4, 5, &ctx->timings.step3_ms);
 }
 
 // one iteration of the reference's timed loop (spgemm.cu:1136-1341): wall clock around
@@ -1613,6 +1675,12 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
     if (!ctx || !plan) return PEM_E_INVALID;
     PEM_HIP(hipSetDevice(ctx->device));
     auto t0 = std::chrono::high_resolution_clock::now();
+    // back-to-back steps share their boundary events (each record is a barrier packet, ~5 us of pipeline bubble)
+    struct Chain {
+        pem_ctx *c;
+        explicit Chain(pem_ctx *c_) : c(c_) { c->chain_events = true; }
+        ~Chain() { c->chain_events = false; }
+    } chain(ctx);
     PEM_TRY(step1_impl(ctx, plan, true));
     PEM_TRY(step2_impl(ctx, plan));
     PEM_TRY(step3_impl(ctx, plan));
@@ -1633,9 +1701,9 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
     PEM_HIP(hipStreamSynchronize(ctx->stream));
     plan->warm = plan->pairs_ready && plan->state == 3;
     ctx->timings.spgemm_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
-    PEM_TRY(step_elapsed(ctx, 0, &ctx->timings.step1_ms));
-    PEM_TRY(step_elapsed(ctx, 2, &ctx->timings.step2_ms));
-    PEM_TRY(step_elapsed(ctx, 4, &ctx->timings.step3_ms));
+    PEM_TRY(step_elapsed(ctx, 0, 1, &ctx->timings.step1_ms));
+    PEM_TRY(step_elapsed(ctx, 1, 3, &ctx->timings.step2_ms));
+    PEM_TRY(step_elapsed(ctx, 3, 5, &ctx->timings.step3_ms));
     return PEM_OK;
 }
 
