@@ -419,16 +419,16 @@ struct S1Row {
             // there the first lane adds the round's population instead
 #pragma unroll
             for (int r = 0; r < EPT; ++r) {
-                if (r >= rpw) break;                       // wave-uniform
-                const bool valid = e0 + r * 64 < n;
+                const bool valid = r < rpw && e0 + r * 64 < n;
                 const unsigned long long vm = __ballot(valid);
-                if (vm == 0) break;
-                const unsigned d = (unsigned)(k[r] >> shift) & 255u;
-                const unsigned d0 = (unsigned)__shfl((int)d, __builtin_ctzll(vm), 64);
-                if (__ballot(valid && d != d0) == 0) {
-                    if (lane == 0) myhist[d0] += (unsigned)__popcll(vm);
-                } else if (valid) {
-                    atomicAdd(&myhist[d], 1u);
+                if (vm != 0) {                             // wave-uniform
+                    const unsigned d = (unsigned)(k[r] >> shift) & 255u;
+                    const unsigned d0 = (unsigned)__shfl((int)d, __builtin_ctzll(vm), 64);
+                    if (__ballot(valid && d != d0) == 0) {
+                        if (lane == 0) myhist[d0] += (unsigned)__popcll(vm);
+                    } else if (valid) {
+                        atomicAdd(&myhist[d], 1u);
+                    }
                 }
             }
             __syncthreads();
@@ -459,15 +459,16 @@ struct S1Row {
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < EPT; ++r) {
-                if (r >= rpw) break;                       // wave-uniform
-                const bool valid = e0 + r * 64 < n;
-                const unsigned d = (unsigned)(k[r] >> shift) & 255u;
-                const unsigned long long m = match_digit(valid, d);
-                if (valid) {
-                    const unsigned base = myhist[d];
-                    const int rank = __popcll(m & lt);
-                    keys[base + rank] = k[r];
-                    if (rank == 0) myhist[d] = base + (unsigned)__popcll(m);
+                if (r < rpw) {                             // wave-uniform
+                    const bool valid = e0 + r * 64 < n;
+                    const unsigned d = (unsigned)(k[r] >> shift) & 255u;
+                    const unsigned long long m = match_digit(valid, d);
+                    if (valid) {
+                        const unsigned base = myhist[d];
+                        const int rank = __popcll(m & lt);
+                        keys[base + rank] = k[r];
+                        if (rank == 0) myhist[d] = base + (unsigned)__popcll(m);
+                    }
                 }
             }
             __syncthreads();
