@@ -28,6 +28,7 @@ def kernel_alg_bytes(name, d):
     once plus every byte it must write once (DESIGN.md 'Kernels and rooflines').  d: sizes."""
     P, TC, NZ = d["npairs"], d["ntiles_c"], d["nnz_c"]
     nA, nB, TA, TB = d["nnz_a"], d["nnz_b"], d["ntiles_a"], d["ntiles_b"]
+    vb = d.get("value_bytes", 8)
     table = {
         "rs_hist_kernel": 8 * P,
         "rs_scatter_kernel": 24 * P,
@@ -37,13 +38,16 @@ def kernel_alg_bytes(name, d):
         "s2_pairs_kernel": 20 * P,
         "s2_cmask_kernel": 8 * P + 32 * TA + 32 * TB + 36 * TC,
         "s2_crowcol_kernel": 36 * TC + 16 * TC + NZ,
-        "s3_accumulate_kernel": 8 * P + 8 * TC + NZ + (8 * nA + 52 * TA) + (8 * nB + 84 * TB) + 8 * NZ,
+        "s3_accumulate_kernel": 8 * P + 8 * TC + NZ + (vb * nA + 52 * TA) + (vb * nB + 84 * TB) + vb * NZ,
         "s2_cmask_wide_kernel": 8 * P + 32 * TA + 32 * TB + 52 * TC,
         "s2_crowcol_wide_kernel": 36 * TC + NZ,
-        "s3_accumulate_wide_kernel": 8 * P + 8 * TC + NZ + (8 * nA + 68 * TA) + (8 * nB + 100 * TB) + 8 * NZ,
+        "s3_accumulate_wide_kernel": 8 * P + 8 * TC + NZ + (vb * nA + 68 * TA) + (vb * nB + 100 * TB) + vb * NZ,
         "s1_rowsort_kernel<512>": None, "s1_rowsort_kernel<2048>": None, "s1_rowsort_kernel<8192>": None,
         "s1_compact_kernel": 20 * TC,
     }
+    for suffix in ("<double>", "<float>"):          # value-typed kernels carry their template argument in the name
+        if name.endswith(suffix):
+            name = name[:-len(suffix)]
     return table.get(name)
 
 
@@ -55,6 +59,8 @@ def main():
     ap.add_argument("--workload", default="webbase-1M", choices=["cage4", "scircuit", "webbase-1M", "mc2depi", "cage15"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the stand-in (tests only; 1.0 = BASELINE size)")
     ap.add_argument("--aat", action="store_true", help="C = A*A^T instead of A^2 (default for mc2depi)")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
+                    help="value type: f64 = the reference's ValueType and BASELINE's metric; f32 = SURVEY 8(f)-3 (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave the C slices on their ranks")
     args = ap.parse_args()
@@ -94,11 +100,15 @@ def main():
     t_gen = time.perf_counter() - t_gen
 
     # inputs resident in HBM before anything is timed
+    import numpy as np
+    np_dt, torch_dt, vbytes = (np.float32, torch.float32, 4) if args.dtype == "f32" else (np.float64, torch.float64, 8)
+    if args.dtype == "f32":
+        V = V.astype(np.float32)
     dI, dJ, dV = torch.from_numpy(I).to(dev), torch.from_numpy(J).to(dev), torch.from_numpy(V).to(dev)
     torch.cuda.synchronize()
     ctx = pkg.Context(dev_index)
-    A = pkg.Tiled.from_coo_device(ctx, rows, cols, len(I), dI.data_ptr(), dJ.data_ptr(), dV.data_ptr(), False)
-    B = pkg.Tiled.from_coo_device(ctx, rows, cols, len(I), dI.data_ptr(), dJ.data_ptr(), dV.data_ptr(), True) if aat else A
+    A = pkg.Tiled.from_coo_device(ctx, rows, cols, len(I), dI.data_ptr(), dJ.data_ptr(), dV.data_ptr(), False, dtype=np_dt)
+    B = pkg.Tiled.from_coo_device(ctx, rows, cols, len(I), dI.data_ptr(), dJ.data_ptr(), dV.data_ptr(), True, dtype=np_dt) if aat else A
     del dI, dJ, dV
     flop = pkg.flop_count(ctx, A, B)
     bounds = pkg.split_tile_rows(ctx, A, B, world)
@@ -119,7 +129,7 @@ def main():
         if bufs.get("nz") != nz:
             bufs.update(nz=nz, rp=torch.empty(nrows + 1, dtype=torch.int32, device=dev),
                         ci=torch.empty(max(nz, 1), dtype=torch.int32, device=dev),
-                        v=torch.empty(max(nz, 1), dtype=torch.float64, device=dev))
+                        v=torch.empty(max(nz, 1), dtype=torch_dt, device=dev))
         plan.export_csr_device(bufs["rp"].data_ptr(), bufs["ci"].data_ptr(), bufs["v"].data_ptr())
         ctx.synchronize()
         bufs["out"] = mg.gather_csr_slices(bufs["rp"], bufs["ci"][:nz], bufs["v"][:nz], dst=0)
@@ -163,7 +173,7 @@ def main():
         plan.spgemm()
     stats = ctx.kernel_stats()
     ctx.set_kernel_profiling(False)
-    dims = dict(npairs=info["npairs"], ntiles_c=info["ntiles_c"], nnz_c=info["nnz_c"], nnz_a=A.nnz, nnz_b=B.nnz,
+    dims = dict(value_bytes=vbytes, npairs=info["npairs"], ntiles_c=info["ntiles_c"], nnz_c=info["nnz_c"], nnz_a=A.nnz, nnz_b=B.nnz,
                 ntiles_a=A.ntiles, ntiles_b=B.ntiles)
     kern = {k: dict(calls_per_step=v["calls"] / nprof, avg_ms=v["total_ms"] / max(v["calls"], 1), ms_per_step=v["total_ms"] / nprof)
             for k, v in stats.items()}
@@ -222,7 +232,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"{args.workload} stand-in (seeded synthetic, scale {args.scale}) {'A*A^T' if aat else 'A^2'}",
                        "rows": rows, "cols": cols, "nnz": int(len(I)), "flop": int(flop), "C_nnz": total_nnz_c, "C_tiles": total_tc,

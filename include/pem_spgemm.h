@@ -67,6 +67,17 @@ pem_status pem_tiled_from_csr(pem_ctx *ctx, int rows, int cols, const int32_t *r
                               const int32_t *colidx, const double *V, pem_tiled **out);
 pem_status pem_tiled_destroy(pem_ctx *ctx, pem_tiled *t);
 
+/* fp32 values.  The reference pins `ValueType = double` in main (spgemm.cu:728) although its kernels
+ * are templates on it (spgemm.cu:137, 593).  The `_f32` entry points build a tiling whose values (and the values of
+ * every C computed from it) are float: step 3 then runs one fmaf per product, in the same ascending-k order.  A and
+ * B of one plan must share a value type; the fp64 export entry points refuse an fp32 plan and vice versa. */
+pem_status pem_tiled_from_coo_f32(pem_ctx *ctx, int rows, int cols, int64_t nnz, const int32_t *I,
+                                  const int32_t *J, const float *V, int transpose, pem_tiled **out);
+pem_status pem_tiled_from_coo_device_f32(pem_ctx *ctx, int rows, int cols, int64_t nnz, const int32_t *dI,
+                                         const int32_t *dJ, const float *dV, int transpose, pem_tiled **out);
+pem_status pem_tiled_from_csr_f32(pem_ctx *ctx, int rows, int cols, const int32_t *rowptr,
+                                  const int32_t *colidx, const float *V, pem_tiled **out);
+
 typedef struct {
     int32_t rows, cols;            /* of the tiled matrix (after transpose)           */
     int64_t nnz;
@@ -74,6 +85,8 @@ typedef struct {
     int64_t ntiles;                /* non-empty 16x16 tiles         spgemm.cu:871     */
     double conv_ms;                /* device time of the whole conversion             */
     double conv_tile_kernel_ms;    /* tile payload kernels only (CSV cols 5/6, spgemm.cu:938-978) */
+    int32_t value_bytes;           /* 8: fp64 (the reference's ValueType), 4: fp32    */
+    int32_t reserved;
 } pem_tiled_info;
 pem_status pem_tiled_get_info(const pem_tiled *t, pem_tiled_info *info);
 
@@ -84,7 +97,7 @@ typedef enum {
     PEM_T_MASKS,             /* uint16[16T] row bitmasks                         spgemm.cu:196-200 */
     PEM_T_ROWPTR,            /* uint8[16T] nnz before row r inside the tile      spgemm.cu:205-209 */
     PEM_T_ROWCOLIDX,         /* uint8[nnz] (r<<4)|c                              spgemm.cu:195, 221 */
-    PEM_T_VALS,              /* double[nnz] tile order, row-major inside a tile  spgemm.cu:220 */
+    PEM_T_VALS,              /* double[nnz] (float[nnz] for an fp32 tiling) tile order, row-major inside a tile  spgemm.cu:220 */
     PEM_T_MASKS_T,           /* uint16[16T] transposed masks                     spgemm.cu:244-253 */
     PEM_T_TILE_ROWPTR,       /* int32[tile_rows+1]                               spgemm.cu:986-999 */
     PEM_T_TILE_COLIDX,       /* int32[T]                                         spgemm.cu:1001-1006 */
@@ -158,7 +171,7 @@ typedef enum {
     PEM_C_TILE_NNZ_PTR,      /* int32[T_C+1]                                    spgemm.cu:546, 1288 */
     PEM_C_ROWPTR,            /* uint8[16 T_C]                                   spgemm.cu:579-580 */
     PEM_C_ROWCOLIDX,         /* uint8[C_nnz]                                    spgemm.cu:582-587 */
-    PEM_C_VALS               /* double[C_nnz]                                   spgemm.cu:643-656 */
+    PEM_C_VALS               /* double[C_nnz] (float for an fp32 plan)          spgemm.cu:643-656 */
 } pem_cplan_array;
 pem_status pem_cplan_get_array(pem_ctx *ctx, const pem_cplan *plan, pem_cplan_array which, void *host_dst, int64_t bytes);
 
@@ -171,6 +184,13 @@ pem_status pem_c_export_csr_device(pem_ctx *ctx, const pem_cplan *plan, int32_t 
                                    int32_t *d_colidx, double *d_vals);
 pem_status pem_c_export_coo(pem_ctx *ctx, const pem_cplan *plan, int64_t *nnz, int32_t *rows,
                             int32_t *cols, double *vals);
+/* the same for a plan over fp32 tilings */
+pem_status pem_c_export_csr_f32(pem_ctx *ctx, const pem_cplan *plan, int64_t *nnz, int32_t *rowptr,
+                                int32_t *colidx, float *vals);
+pem_status pem_c_export_csr_device_f32(pem_ctx *ctx, const pem_cplan *plan, int32_t *d_rowptr,
+                                       int32_t *d_colidx, float *d_vals);
+pem_status pem_c_export_coo_f32(pem_ctx *ctx, const pem_cplan *plan, int64_t *nnz, int32_t *rows,
+                                int32_t *cols, float *vals);
 
 /* ---- multi-GPU helper: balanced tile-row split (new) ----------------------- */
 /* bounds[0..nparts] tile-row boundaries of A, balanced on the per-tile-row intermediate

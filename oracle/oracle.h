@@ -94,6 +94,8 @@ int  oracle_spgemm_step1(const oracle_tiled *A, const oracle_tiled *B, int tr_lo
                          oracle_cplan *p);
 int  oracle_spgemm_step2(const oracle_tiled *A, const oracle_tiled *B, oracle_cplan *p);
 int  oracle_spgemm_step3(const oracle_tiled *A, const oracle_tiled *B, oracle_cplan *p);
+/* fp32 chain: operands must be float-representable; c_vals holds the float results widened */
+int  oracle_spgemm_step3_f32(const oracle_tiled *A, const oracle_tiled *B, oracle_cplan *p);
 void oracle_cplan_free(oracle_cplan *p);
 
 /* a14: tiled C -> COO sorted by (row, col) (spgemm.cu:663-695, 1516-1519), caller
@@ -110,6 +112,7 @@ int  oracle_csr_from_coo(int rows, int cols, int nnz, const int *I, const int *J
 /* C = A*B, sorted columns, ascending-k accumulation with one fma per product, structural
  * zeros kept.  threads<=1: serial; >1: OpenMP row-parallel (same arithmetic, same result). */
 int  oracle_csr_spgemm(const oracle_csr *A, const oracle_csr *B, int threads, oracle_csr *C);
+int  oracle_csr_spgemm_f32(const oracle_csr *A, const oracle_csr *B, int threads, oracle_csr *C);   /* float chain, fmaf */
 void oracle_csr_free(oracle_csr *m);
 int  oracle_max_threads(void);
 

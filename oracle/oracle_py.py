@@ -129,14 +129,15 @@ def flop_count(A, B):
 class Plan:
     """a9-a14 for C = A*B over A's tile rows [tr_lo, tr_hi)."""
 
-    def __init__(self, A, B, tr_lo=0, tr_hi=None):
+    def __init__(self, A, B, tr_lo=0, tr_hi=None, f32=False):
+        """f32: step 3 runs the float chain (operands must be float-representable; c_vals are the float results widened)."""
         self.A, self.B = A, B
         tr_hi = A.tile_rows if tr_hi is None else tr_hi
         self._s = _Plan()
         L = lib()
         for fn, args in ((L.oracle_spgemm_step1, (C.byref(A._s), C.byref(B._s), int(tr_lo), int(tr_hi), C.byref(self._s))),
                          (L.oracle_spgemm_step2, (C.byref(A._s), C.byref(B._s), C.byref(self._s))),
-                         (L.oracle_spgemm_step3, (C.byref(A._s), C.byref(B._s), C.byref(self._s)))):
+                         (L.oracle_spgemm_step3_f32 if f32 else L.oracle_spgemm_step3, (C.byref(A._s), C.byref(B._s), C.byref(self._s)))):
             rc = fn(*args)
             if rc != 0:
                 raise ValueError(f"oracle step -> {rc}")
@@ -201,9 +202,10 @@ class Csr:
             pass
 
 
-def csr_spgemm(A, B, threads=1):
+def csr_spgemm(A, B, threads=1, f32=False):
     out = Csr()
-    rc = lib().oracle_csr_spgemm(C.byref(A._s), C.byref(B._s), int(threads), C.byref(out._s))
+    fn = lib().oracle_csr_spgemm_f32 if f32 else lib().oracle_csr_spgemm
+    rc = fn(C.byref(A._s), C.byref(B._s), int(threads), C.byref(out._s))
     if rc != 0:
         raise ValueError(f"oracle_csr_spgemm -> {rc}")
     return out

@@ -65,6 +65,10 @@ int oracle_csr_from_coo(int rows, int cols, int nnz, const int *I_in, const int 
     return 0;
 }
 
+/* with g_f32 set the chain runs in float (operands are float values held in doubles, one fmaf per
+ * product, result widened exactly) -- the checker of the fp32 product path. */
+static int g_f32 = 0;
+
 /* one row: returns the number of distinct columns; if col/val != NULL also writes them sorted */
 static int row_product(const oracle_csr *A, const oracle_csr *B, int i, int *marker, double *acc,
                        int *list, int *col, double *val)
@@ -76,7 +80,7 @@ static int row_product(const oracle_csr *A, const oracle_csr *B, int i, int *mar
         for (int eb = B->rowptr[k]; eb < B->rowptr[k + 1]; ++eb) {
             int j = B->col[eb];
             if (marker[j] != i) { marker[j] = i; acc[j] = 0.0; list[cnt++] = j; }
-            acc[j] = fma(a, B->val[eb], acc[j]);
+            acc[j] = g_f32 ? (double)fmaf((float)a, (float)B->val[eb], (float)acc[j]) : fma(a, B->val[eb], acc[j]);
         }
     }
     if (col) {
@@ -137,4 +141,12 @@ int oracle_csr_spgemm(const oracle_csr *A, const oracle_csr *B, int threads, ora
         free(marker); free(acc); free(list);
     }
     return 0;
+}
+
+int oracle_csr_spgemm_f32(const oracle_csr *A, const oracle_csr *B, int threads, oracle_csr *C)
+{
+    g_f32 = 1;
+    int rc = oracle_csr_spgemm(A, B, threads, C);
+    g_f32 = 0;
+    return rc;
 }

@@ -352,7 +352,7 @@ int oracle_spgemm_step2(const oracle_tiled *A, const oracle_tiled *B, oracle_cpl
  * pairs in ascending k-tile order, bits of Amask[r]&BT[c] ascending, one multiply-add per
  * product (nvcc contracts `+= a*b` to an FMA by default).  The reference accumulates into
  * never-zeroed memory; the restatement starts from +0.0. */
-int oracle_spgemm_step3(const oracle_tiled *A, const oracle_tiled *B, oracle_cplan *p)
+static int step3_impl(const oracle_tiled *A, const oracle_tiled *B, oracle_cplan *p, int f32)
 {
     p->c_vals = ALLOC(double, p->nnz_c);
     for (int t = 0; t < p->ntiles_c; ++t) {
@@ -370,7 +370,7 @@ int oracle_spgemm_step3(const oracle_tiled *A, const oracle_tiled *B, oracle_cpl
                     int b_o = popc16(B->masks[16 * (size_t)b + ffs] & (0xFFFFu >> (16 - c)));          /* :652 */
                     double av = A->vals[aoff + A->rowptr[16 * (size_t)a + r] + a_o];
                     double bv = B->vals[boff + B->rowptr[16 * (size_t)b + ffs] + b_o];
-                    acc = fma(av, bv, acc);                                                /* :653 */
+                    acc = f32 ? (double)fmaf((float)av, (float)bv, (float)acc) : fma(av, bv, acc);   /* :653 */
                     lane_mask &= ~(1u << ffs);                                             /* :655 */
                 }
             }
@@ -379,6 +379,12 @@ int oracle_spgemm_step3(const oracle_tiled *A, const oracle_tiled *B, oracle_cpl
     }
     return 0;
 }
+
+int oracle_spgemm_step3(const oracle_tiled *A, const oracle_tiled *B, oracle_cplan *p) { return step3_impl(A, B, p, 0); }
+
+/* the same chain in float -- operands are float values held in doubles, one fmaf per product (the
+ * reference's kernel is a template on ValueType, spgemm.cu:593; only main pins double, spgemm.cu:728). */
+int oracle_spgemm_step3_f32(const oracle_tiled *A, const oracle_tiled *B, oracle_cplan *p) { return step3_impl(A, B, p, 1); }
 
 /* a14 sanitize_C (spgemm.cu:663-695) + stable_sort by (row, col, val) (spgemm.cu:1516-1519).
  * (row, col) pairs are unique, so the order is fully determined by (row, col). */

@@ -35,6 +35,8 @@ ABI_SYMBOLS = [
     "pem_spgemm_step3", "pem_spgemm", "pem_cplan_get_info", "pem_cplan_get_array", "pem_c_export_csr", "pem_c_export_csr_device",
     "pem_c_export_coo", "pem_split_tile_rows", "pem_get_timings", "pem_set_kernel_profiling", "pem_reset_kernel_stats",
     "pem_kernel_stats_count", "pem_kernel_stats_get", "pem_tiled_save", "pem_tiled_load",
+    "pem_tiled_from_coo_f32", "pem_tiled_from_coo_device_f32", "pem_tiled_from_csr_f32", "pem_c_export_csr_f32",
+    "pem_c_export_csr_device_f32", "pem_c_export_coo_f32",
 ]
 
 
@@ -46,7 +48,8 @@ class PemError(RuntimeError):
 
 class TiledInfo(C.Structure):
     _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("nnz", C.c_int64), ("tile_rows", C.c_int32), ("tile_cols", C.c_int32),
-                ("ntiles", C.c_int64), ("conv_ms", C.c_double), ("conv_tile_kernel_ms", C.c_double)]
+                ("ntiles", C.c_int64), ("conv_ms", C.c_double), ("conv_tile_kernel_ms", C.c_double), ("value_bytes", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class CPlanInfo(C.Structure):
@@ -157,34 +160,44 @@ class Tiled:
         for k, _ in TiledInfo._fields_:
             setattr(self, k, getattr(info, k))
 
+    @property
+    def dtype(self):
+        return np.dtype(np.float32 if self.value_bytes == 4 else np.float64)
+
     @classmethod
-    def from_coo(cls, ctx, rows, cols, I, J, V, transpose=False):
+    def from_coo(cls, ctx, rows, cols, I, J, V, transpose=False, dtype=np.float64):
+        """dtype float64 (the reference's ValueType) or float32 (values are rounded to float here)."""
+        f32 = np.dtype(dtype) == np.float32
         I = np.ascontiguousarray(I, dtype=np.int32)
         J = np.ascontiguousarray(J, dtype=np.int32)
-        V = np.ascontiguousarray(V, dtype=np.float64)
+        V = np.ascontiguousarray(V, dtype=np.float32 if f32 else np.float64)
         if not (len(I) == len(J) == len(V)):
             raise ValueError("I, J, V lengths differ")
         h = C.c_void_p()
-        _check(lib().pem_tiled_from_coo(ctx._h, int(rows), int(cols), C.c_int64(len(I)), _p(I, C.c_int32), _p(J, C.c_int32),
-                                        _p(V, C.c_double), int(bool(transpose)), C.byref(h)))
+        fn = lib().pem_tiled_from_coo_f32 if f32 else lib().pem_tiled_from_coo
+        _check(fn(ctx._h, int(rows), int(cols), C.c_int64(len(I)), _p(I, C.c_int32), _p(J, C.c_int32),
+                  _p(V, C.c_float if f32 else C.c_double), int(bool(transpose)), C.byref(h)))
         return cls(ctx, h)
 
     @classmethod
-    def from_coo_device(cls, ctx, rows, cols, nnz, dI, dJ, dV, transpose=False):
-        """dI/dJ/dV: device pointers (ints), e.g. torch tensors' data_ptr()."""
+    def from_coo_device(cls, ctx, rows, cols, nnz, dI, dJ, dV, transpose=False, dtype=np.float64):
+        """dI/dJ/dV: device pointers (ints), e.g. torch tensors' data_ptr(); dV points at `dtype` values."""
         h = C.c_void_p()
-        _check(lib().pem_tiled_from_coo_device(ctx._h, int(rows), int(cols), C.c_int64(nnz), C.c_void_p(dI), C.c_void_p(dJ),
-                                               C.c_void_p(dV), int(bool(transpose)), C.byref(h)))
+        fn = lib().pem_tiled_from_coo_device_f32 if np.dtype(dtype) == np.float32 else lib().pem_tiled_from_coo_device
+        _check(fn(ctx._h, int(rows), int(cols), C.c_int64(nnz), C.c_void_p(dI), C.c_void_p(dJ), C.c_void_p(dV), int(bool(transpose)),
+                  C.byref(h)))
         return cls(ctx, h)
 
     @classmethod
-    def from_csr(cls, ctx, rows, cols, rowptr, colidx, V):
+    def from_csr(cls, ctx, rows, cols, rowptr, colidx, V, dtype=np.float64):
+        f32 = np.dtype(dtype) == np.float32
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int32)
         colidx = np.ascontiguousarray(colidx, dtype=np.int32)
-        V = np.ascontiguousarray(V, dtype=np.float64)
+        V = np.ascontiguousarray(V, dtype=np.float32 if f32 else np.float64)
         h = C.c_void_p()
-        _check(lib().pem_tiled_from_csr(ctx._h, int(rows), int(cols), _p(rowptr, C.c_int32), _p(colidx, C.c_int32), _p(V, C.c_double),
-                                        C.byref(h)))
+        fn = lib().pem_tiled_from_csr_f32 if f32 else lib().pem_tiled_from_csr
+        _check(fn(ctx._h, int(rows), int(cols), _p(rowptr, C.c_int32), _p(colidx, C.c_int32), _p(V, C.c_float if f32 else C.c_double),
+                  C.byref(h)))
         return cls(ctx, h)
 
     def save(self, path, key=None):
@@ -205,6 +218,8 @@ class Tiled:
 
     def array(self, name):
         which, dt = T_ARRAYS[name]
+        if name == "vals":
+            dt = self.dtype
         out = np.zeros(self._count(name), dtype=dt)
         _check(lib().pem_tiled_get_array(self.ctx._h, self._h, which, out.ctypes.data_as(C.c_void_p), C.c_int64(out.nbytes)))
         return out
@@ -264,6 +279,8 @@ class CPlan:
         TC, P, NZ, mt = i["ntiles_c"], i["npairs"], i["nnz_c"], i["tile_row_end"] - i["tile_row_begin"]
         cnt = dict(c_tile_rowptr=mt + 1, c_tile_rowidx=TC, c_tile_colidx=TC, pairs_offset=TC + 1, pairs_a=P, pairs_b=P, c_mask=8 * TC,
                    c_tile_nnz_ptr=TC + 1, c_rowptr=16 * TC, c_rowcolidx=NZ, c_vals=NZ)[name]
+        if name == "c_vals":
+            dt = self.A.dtype
         out = np.zeros(cnt, dtype=dt)
         _check(lib().pem_cplan_get_array(self.ctx._h, self._h, which, out.ctypes.data_as(C.c_void_p), C.c_int64(out.nbytes)))
         return out
@@ -271,19 +288,25 @@ class CPlan:
     def export_csr(self):
         i = self.info()
         nrows, nz = i["row_end"] - i["row_begin"], i["nnz_c"]
-        rp, ci, v = np.zeros(nrows + 1, np.int32), np.zeros(nz, np.int32), np.zeros(nz, np.float64)
+        f32 = self.A.value_bytes == 4
+        rp, ci, v = np.zeros(nrows + 1, np.int32), np.zeros(nz, np.int32), np.zeros(nz, self.A.dtype)
         n = C.c_int64()
-        _check(lib().pem_c_export_csr(self.ctx._h, self._h, C.byref(n), _p(rp, C.c_int32), _p(ci, C.c_int32), _p(v, C.c_double)))
+        fn = lib().pem_c_export_csr_f32 if f32 else lib().pem_c_export_csr
+        _check(fn(self.ctx._h, self._h, C.byref(n), _p(rp, C.c_int32), _p(ci, C.c_int32), _p(v, C.c_float if f32 else C.c_double)))
         return rp, ci, v
 
     def export_csr_device(self, d_rowptr, d_colidx, d_vals):
-        _check(lib().pem_c_export_csr_device(self.ctx._h, self._h, C.c_void_p(d_rowptr), C.c_void_p(d_colidx), C.c_void_p(d_vals)))
+        """d_vals points at values of the plan's type (float64, or float32 for fp32 tilings)."""
+        fn = lib().pem_c_export_csr_device_f32 if self.A.value_bytes == 4 else lib().pem_c_export_csr_device
+        _check(fn(self.ctx._h, self._h, C.c_void_p(d_rowptr), C.c_void_p(d_colidx), C.c_void_p(d_vals)))
 
     def export_coo(self):
         nz = self.info()["nnz_c"]
-        r, c, v = np.zeros(nz, np.int32), np.zeros(nz, np.int32), np.zeros(nz, np.float64)
+        f32 = self.A.value_bytes == 4
+        r, c, v = np.zeros(nz, np.int32), np.zeros(nz, np.int32), np.zeros(nz, self.A.dtype)
         n = C.c_int64()
-        _check(lib().pem_c_export_coo(self.ctx._h, self._h, C.byref(n), _p(r, C.c_int32), _p(c, C.c_int32), _p(v, C.c_double)))
+        fn = lib().pem_c_export_coo_f32 if f32 else lib().pem_c_export_coo
+        _check(fn(self.ctx._h, self._h, C.byref(n), _p(r, C.c_int32), _p(c, C.c_int32), _p(v, C.c_float if f32 else C.c_double)))
         return r, c, v
 
     def close(self):

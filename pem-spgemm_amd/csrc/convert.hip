@@ -75,8 +75,9 @@ __global__ void conv_heads_kernel(const uint64_t *__restrict__ keys, size_t nnz,
 
 // a5 payload (spgemm.cu:195, 218-222): values + (r<<4|c) bytes in tile order; tile list +
 // perTileNnz offsets (spgemm.cu:873-877).  headx = exclusive scan of the head flags.
+template <typename VT>
 __global__ void conv_fill_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm, const int *__restrict__ headx,
-                                 size_t nnz, const double *__restrict__ V, int bits_tc, double *__restrict__ vals,
+                                 size_t nnz, const VT *__restrict__ V, int bits_tc, VT *__restrict__ vals,
                                  uint8_t *__restrict__ rowcolidx, long long *__restrict__ tile_keys, int *__restrict__ tile_nnz_ptr)
 {
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -154,9 +155,10 @@ __global__ void __launch_bounds__(256) conv_tile_meta_kernel(const uint8_t *__re
 
 // column-major copy of every tile's values: entry (rr, c) of tile t goes to slot (entries in columns < c) + (rows < rr
 // holding column c).  headx = exclusive scan of the tile-head flags (tile of entry e = headx[e] - !is_head).
-__global__ void conv_vals_t_kernel(const uint8_t *__restrict__ rowcolidx, const double *__restrict__ vals, const int *__restrict__ headx,
+template <typename VT>
+__global__ void conv_vals_t_kernel(const uint8_t *__restrict__ rowcolidx, const VT *__restrict__ vals, const int *__restrict__ headx,
                                    size_t nnz, const int *__restrict__ tile_nnz_ptr, const uint32_t *__restrict__ rec_t,
-                                   double *__restrict__ vals_t)
+                                   VT *__restrict__ vals_t)
 {
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nnz) return;
@@ -389,7 +391,7 @@ static pem_status derive_tiled(pem_ctx *ctx, pem_tiled *T, const int *headx, int
     PEM_TRY(T->tile_rec.reserve(sizeof(uint32_t) * 16 * (nt + 1)));
     PEM_TRY(T->tile_occ.reserve(sizeof(uint32_t) * (nt + 4)));
     PEM_TRY(T->tile_rec_t.reserve(sizeof(uint32_t) * 16 * (nt + 1)));
-    PEM_TRY(T->vals_t.reserve(sizeof(double) * (nnz + 1)));
+    PEM_TRY(T->vals_t.reserve((size_t)T->value_bytes * (nnz + 1)));
     PEM_TRY(T->tile_rowptr.reserve(sizeof(int) * ((size_t)T->tile_rows + 4)));
     PEM_TRY(T->tile_colidx.reserve(sizeof(int) * (nt + 4)));
     PEM_TRY(T->tile_colptr.reserve(sizeof(int) * ((size_t)T->tile_cols + 4)));
@@ -401,8 +403,12 @@ static pem_status derive_tiled(pem_ctx *ctx, pem_tiled *T, const int *headx, int
         PEM_LAUNCH(ctx, conv_tile_meta_kernel, grid_for(nt * 16, 256), 256, T->rowcolidx.as<uint8_t>(), T->tile_nnz_ptr.as<int>(),
                    (long long)ntiles, T->masks.as<uint16_t>(), T->rowptr.as<uint8_t>(), T->masks_t.as<uint16_t>(), T->tile_rec.as<uint32_t>(),
                    T->tile_occ.as<uint32_t>(), T->tile_rec_t.as<uint32_t>());
-        PEM_LAUNCH(ctx, conv_vals_t_kernel, grid_for(nnz, 256), 256, T->rowcolidx.as<uint8_t>(), T->vals.as<double>(), headx, nnz,
-                   T->tile_nnz_ptr.as<int>(), T->tile_rec_t.as<uint32_t>(), T->vals_t.as<double>());
+        if (T->value_bytes == 4)
+            PEM_LAUNCH(ctx, conv_vals_t_kernel<float>, grid_for(nnz, 256), 256, T->rowcolidx.as<uint8_t>(), T->vals.as<float>(), headx, nnz,
+                       T->tile_nnz_ptr.as<int>(), T->tile_rec_t.as<uint32_t>(), T->vals_t.as<float>());
+        else
+            PEM_LAUNCH(ctx, conv_vals_t_kernel<double>, grid_for(nnz, 256), 256, T->rowcolidx.as<uint8_t>(), T->vals.as<double>(), headx, nnz,
+                       T->tile_nnz_ptr.as<int>(), T->tile_rec_t.as<uint32_t>(), T->vals_t.as<double>());
     }
     PEM_HIP(hipEventRecord(ctx->ev[7], st));
     if (nt) {
@@ -432,7 +438,7 @@ static pem_status derive_tiled(pem_ctx *ctx, pem_tiled *T, const int *headx, int
 }
 
 // keys/perm already filled in k0/v0 (nnz entries); V = device values in input order.
-static pem_status build_tiled(pem_ctx *ctx, pem_tiled *T, DevBuf &k0, DevBuf &k1, DevBuf &v0, DevBuf &v1, const double *dV,
+static pem_status build_tiled(pem_ctx *ctx, pem_tiled *T, DevBuf &k0, DevBuf &k1, DevBuf &v0, DevBuf &v1, const void *dV,
                               int bits_tr, int bits_tc)
 {
     const size_t nnz = (size_t)T->nnz;
@@ -462,18 +468,21 @@ static pem_status build_tiled(pem_ctx *ctx, pem_tiled *T, DevBuf &k0, DevBuf &k1
     const size_t nt = (size_t)ntiles;
     PEM_TRY(T->tile_keys.reserve(sizeof(long long) * (nt + 1)));
     PEM_TRY(T->tile_nnz_ptr.reserve(sizeof(int) * (nt + 4)));
-    PEM_TRY(T->vals.reserve(sizeof(double) * (nnz + 1)));
+    PEM_TRY(T->vals.reserve((size_t)T->value_bytes * (nnz + 1)));
     PEM_TRY(T->rowcolidx.reserve(nnz + 16));
     PEM_HIP(hipMemsetAsync(T->tile_nnz_ptr.p, 0, sizeof(int) * (nt + 1), st));
     PEM_HIP(hipEventRecord(ctx->ev[6], st));
-    if (nnz)
-        PEM_LAUNCH(ctx, conv_fill_kernel, grid_for(nnz, 256), 256, keys, perm, head.as<int>(), nnz, dV, bits_tc, T->vals.as<double>(),
-                   T->rowcolidx.as<uint8_t>(), T->tile_keys.as<long long>(), T->tile_nnz_ptr.as<int>());
+    if (nnz && T->value_bytes == 4)
+        PEM_LAUNCH(ctx, conv_fill_kernel<float>, grid_for(nnz, 256), 256, keys, perm, head.as<int>(), nnz, static_cast<const float *>(dV), bits_tc,
+                   T->vals.as<float>(), T->rowcolidx.as<uint8_t>(), T->tile_keys.as<long long>(), T->tile_nnz_ptr.as<int>());
+    else if (nnz)
+        PEM_LAUNCH(ctx, conv_fill_kernel<double>, grid_for(nnz, 256), 256, keys, perm, head.as<int>(), nnz, static_cast<const double *>(dV), bits_tc,
+                   T->vals.as<double>(), T->rowcolidx.as<uint8_t>(), T->tile_keys.as<long long>(), T->tile_nnz_ptr.as<int>());
     return derive_tiled(ctx, T, head.as<int>(), bits_tr, bits_tc);
 }
 
 static pem_status tiled_from_device(pem_ctx *ctx, int rows, int cols, int64_t nnz, const int *dI, const int *dJ, const int *d_rowptr,
-                                    const double *dV, int transpose, pem_tiled **out)
+                                    const void *dV, int value_bytes, int transpose, pem_tiled **out)
 {
     if (!ctx || !out || rows <= 0 || cols <= 0 || nnz < 0) {
         set_error("pem_tiled_from_*: bad arguments (rows=%d cols=%d nnz=%lld)", rows, cols, (long long)nnz);
@@ -487,6 +496,7 @@ static pem_status tiled_from_device(pem_ctx *ctx, int rows, int cols, int64_t nn
     PEM_HIP(hipSetDevice(ctx->device));
     auto t0 = std::chrono::high_resolution_clock::now();
     pem_tiled *T = new pem_tiled();
+    T->value_bytes = value_bytes;
     T->rows = transpose ? cols : rows;
     T->cols = transpose ? rows : cols;
     T->nnz = nnz;
@@ -522,15 +532,8 @@ static pem_status tiled_from_device(pem_ctx *ctx, int rows, int cols, int64_t nn
     return PEM_OK;
 }
 
-extern "C" pem_status pem_tiled_from_coo_device(pem_ctx *ctx, int rows, int cols, int64_t nnz, const int32_t *dI, const int32_t *dJ,
-                                                const double *dV, int transpose, pem_tiled **out)
-{
-    if (nnz > 0 && (!dI || !dJ || !dV)) return PEM_E_INVALID;
-    return tiled_from_device(ctx, rows, cols, nnz, dI, dJ, nullptr, dV, transpose, out);
-}
-
-extern "C" pem_status pem_tiled_from_coo(pem_ctx *ctx, int rows, int cols, int64_t nnz, const int32_t *I, const int32_t *J,
-                                         const double *V, int transpose, pem_tiled **out)
+static pem_status from_coo_host(pem_ctx *ctx, int rows, int cols, int64_t nnz, const int32_t *I, const int32_t *J, const void *V,
+                                int value_bytes, int transpose, pem_tiled **out)
 {
     if (!ctx || nnz < 0 || (nnz > 0 && (!I || !J || !V))) return PEM_E_INVALID;
     PEM_HIP(hipSetDevice(ctx->device));
@@ -538,19 +541,19 @@ extern "C" pem_status pem_tiled_from_coo(pem_ctx *ctx, int rows, int cols, int64
     const size_t n = (size_t)nnz;
     PEM_TRY(dI.reserve(sizeof(int) * (n + 1)));
     PEM_TRY(dJ.reserve(sizeof(int) * (n + 1)));
-    PEM_TRY(dV.reserve(sizeof(double) * (n + 1)));
+    PEM_TRY(dV.reserve((size_t)value_bytes * (n + 1)));
     if (n) {   // H2D of the COO triplets (spgemm.cu:832-838)
         PEM_HIP(hipMemcpyAsync(dI.p, I, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
         PEM_HIP(hipMemcpyAsync(dJ.p, J, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
-        PEM_HIP(hipMemcpyAsync(dV.p, V, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+        PEM_HIP(hipMemcpyAsync(dV.p, V, (size_t)value_bytes * n, hipMemcpyHostToDevice, ctx->stream));
     }
-    pem_status s = tiled_from_device(ctx, rows, cols, nnz, dI.as<int>(), dJ.as<int>(), nullptr, dV.as<double>(), transpose, out);
+    pem_status s = tiled_from_device(ctx, rows, cols, nnz, dI.as<int>(), dJ.as<int>(), nullptr, dV.p, value_bytes, transpose, out);
     (void)hipStreamSynchronize(ctx->stream);
     return s;
 }
 
-extern "C" pem_status pem_tiled_from_csr(pem_ctx *ctx, int rows, int cols, const int32_t *rowptr, const int32_t *colidx, const double *V,
-                                         pem_tiled **out)
+static pem_status from_csr_host(pem_ctx *ctx, int rows, int cols, const int32_t *rowptr, const int32_t *colidx, const void *V, int value_bytes,
+                                pem_tiled **out)
 {
     if (!ctx || !rowptr || rows <= 0) return PEM_E_INVALID;
     for (int r = 0; r < rows; ++r)
@@ -565,15 +568,53 @@ extern "C" pem_status pem_tiled_from_csr(pem_ctx *ctx, int rows, int cols, const
     const size_t n = (size_t)nnz;
     PEM_TRY(dR.reserve(sizeof(int) * ((size_t)rows + 1)));
     PEM_TRY(dJ.reserve(sizeof(int) * (n + 1)));
-    PEM_TRY(dV.reserve(sizeof(double) * (n + 1)));
+    PEM_TRY(dV.reserve((size_t)value_bytes * (n + 1)));
     PEM_HIP(hipMemcpyAsync(dR.p, rowptr, sizeof(int) * ((size_t)rows + 1), hipMemcpyHostToDevice, ctx->stream));
     if (n) {
         PEM_HIP(hipMemcpyAsync(dJ.p, colidx, sizeof(int) * n, hipMemcpyHostToDevice, ctx->stream));
-        PEM_HIP(hipMemcpyAsync(dV.p, V, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+        PEM_HIP(hipMemcpyAsync(dV.p, V, (size_t)value_bytes * n, hipMemcpyHostToDevice, ctx->stream));
     }
-    pem_status s = tiled_from_device(ctx, rows, cols, nnz, nullptr, dJ.as<int>(), dR.as<int>(), dV.as<double>(), 0, out);
+    pem_status s = tiled_from_device(ctx, rows, cols, nnz, nullptr, dJ.as<int>(), dR.as<int>(), dV.p, value_bytes, 0, out);
     (void)hipStreamSynchronize(ctx->stream);
     return s;
+}
+
+extern "C" pem_status pem_tiled_from_coo_device(pem_ctx *ctx, int rows, int cols, int64_t nnz, const int32_t *dI, const int32_t *dJ,
+                                                const double *dV, int transpose, pem_tiled **out)
+{
+    if (nnz > 0 && (!dI || !dJ || !dV)) return PEM_E_INVALID;
+    return tiled_from_device(ctx, rows, cols, nnz, dI, dJ, nullptr, dV, 8, transpose, out);
+}
+
+extern "C" pem_status pem_tiled_from_coo_device_f32(pem_ctx *ctx, int rows, int cols, int64_t nnz, const int32_t *dI, const int32_t *dJ,
+                                                    const float *dV, int transpose, pem_tiled **out)
+{
+    if (nnz > 0 && (!dI || !dJ || !dV)) return PEM_E_INVALID;
+    return tiled_from_device(ctx, rows, cols, nnz, dI, dJ, nullptr, dV, 4, transpose, out);
+}
+
+extern "C" pem_status pem_tiled_from_coo(pem_ctx *ctx, int rows, int cols, int64_t nnz, const int32_t *I, const int32_t *J,
+                                         const double *V, int transpose, pem_tiled **out)
+{
+    return from_coo_host(ctx, rows, cols, nnz, I, J, V, 8, transpose, out);
+}
+
+extern "C" pem_status pem_tiled_from_coo_f32(pem_ctx *ctx, int rows, int cols, int64_t nnz, const int32_t *I, const int32_t *J,
+                                             const float *V, int transpose, pem_tiled **out)
+{
+    return from_coo_host(ctx, rows, cols, nnz, I, J, V, 4, transpose, out);
+}
+
+extern "C" pem_status pem_tiled_from_csr(pem_ctx *ctx, int rows, int cols, const int32_t *rowptr, const int32_t *colidx, const double *V,
+                                         pem_tiled **out)
+{
+    return from_csr_host(ctx, rows, cols, rowptr, colidx, V, 8, out);
+}
+
+extern "C" pem_status pem_tiled_from_csr_f32(pem_ctx *ctx, int rows, int cols, const int32_t *rowptr, const int32_t *colidx, const float *V,
+                                             pem_tiled **out)
+{
+    return from_csr_host(ctx, rows, cols, rowptr, colidx, V, 4, out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -636,14 +677,14 @@ uint64_t hash64(const void *data, size_t bytes, uint64_t seed)
 struct CacheLayout {
     size_t off_keys, off_ptr, off_rc, off_vals, total;
 };
-CacheLayout cache_layout(int64_t nnz, int64_t ntiles)
+CacheLayout cache_layout(int64_t nnz, int64_t ntiles, int value_bytes)
 {
     CacheLayout L;
     L.off_keys = 0;
     L.off_ptr = L.off_keys + pad64(sizeof(long long) * (size_t)ntiles);
     L.off_rc = L.off_ptr + pad64(sizeof(int) * ((size_t)ntiles + 1));
     L.off_vals = L.off_rc + pad64((size_t)nnz);
-    L.total = L.off_vals + pad64(sizeof(double) * (size_t)nnz);
+    L.total = L.off_vals + pad64((size_t)value_bytes * (size_t)nnz);
     return L;
 }
 }   // namespace
@@ -687,7 +728,7 @@ extern "C" pem_status pem_tiled_save(pem_ctx *ctx, const pem_tiled *T, const cha
 {
     if (!ctx || !T || !path || !*path) return PEM_E_INVALID;
     PEM_HIP(hipSetDevice(ctx->device));
-    const CacheLayout L = cache_layout(T->nnz, T->ntiles);
+    const CacheLayout L = cache_layout(T->nnz, T->ntiles, T->value_bytes);
     std::vector<unsigned char> buf(sizeof(CacheHeader) + L.total, 0);
     unsigned char *payload = buf.data() + sizeof(CacheHeader);
     const size_t nt = (size_t)T->ntiles, nnz = (size_t)T->nnz;
@@ -698,7 +739,7 @@ extern "C" pem_status pem_tiled_save(pem_ctx *ctx, const pem_tiled *T, const cha
     }
     if (nnz) {
         PEM_HIP(hipMemcpyAsync(payload + L.off_rc, T->rowcolidx.p, nnz, hipMemcpyDeviceToHost, st));
-        PEM_HIP(hipMemcpyAsync(payload + L.off_vals, T->vals.p, sizeof(double) * nnz, hipMemcpyDeviceToHost, st));
+        PEM_HIP(hipMemcpyAsync(payload + L.off_vals, T->vals.p, (size_t)T->value_bytes * nnz, hipMemcpyDeviceToHost, st));
     }
     PEM_HIP(hipStreamSynchronize(st));
     CacheHeader h;
@@ -706,7 +747,7 @@ extern "C" pem_status pem_tiled_save(pem_ctx *ctx, const pem_tiled *T, const cha
     memcpy(h.magic, CACHE_MAGIC, 8);
     h.version = 1;
     h.tile_size = 16;
-    h.value_bytes = 8;
+    h.value_bytes = (uint32_t)T->value_bytes;
     h.header_bytes = sizeof(CacheHeader);
     h.rows = T->rows;
     h.cols = T->cols;
@@ -759,12 +800,12 @@ extern "C" pem_status pem_tiled_load(pem_ctx *ctx, const char *path, const pem_c
         z.header_hash = 0;
         if (hash64(&z, sizeof z, 0x6865616465723031ull) != h.header_hash) return fail("header checksum mismatch");
     }
-    if (h.version != 1 || h.tile_size != 16 || h.value_bytes != 8 || h.header_bytes != sizeof(CacheHeader))
+    if (h.version != 1 || h.tile_size != 16 || (h.value_bytes != 8 && h.value_bytes != 4) || h.header_bytes != sizeof(CacheHeader))
         return fail("unsupported cache version, tile size or value type");
     if (h.rows <= 0 || h.cols <= 0 || h.nnz < 0 || h.nnz > 0x7FFFFFFFll || h.ntiles < 0 || h.ntiles > h.nnz ||
         (h.nnz > 0 && h.ntiles == 0))
         return fail("impossible dimensions in the header");
-    const CacheLayout L = cache_layout(h.nnz, h.ntiles);
+    const CacheLayout L = cache_layout(h.nnz, h.ntiles, (int)h.value_bytes);
     if (h.payload_bytes != L.total) return fail("payload size does not match the dimensions");
     if (expect && (expect->source_size != h.key.source_size || expect->source_mtime_ns != h.key.source_mtime_ns ||
                    expect->transpose != h.key.transpose)) {
@@ -792,6 +833,7 @@ extern "C" pem_status pem_tiled_load(pem_ctx *ctx, const char *path, const pem_c
     PEM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     pem_tiled *T = new pem_tiled();
+    T->value_bytes = (int)h.value_bytes;
     T->rows = h.rows;
     T->cols = h.cols;
     T->nnz = h.nnz;
@@ -804,7 +846,7 @@ extern "C" pem_status pem_tiled_load(pem_ctx *ctx, const char *path, const pem_c
         PEM_TRY(zero_flags(ctx));
         PEM_TRY(T->tile_keys.reserve(sizeof(long long) * (nt + 1)));
         PEM_TRY(T->tile_nnz_ptr.reserve(sizeof(int) * (nt + 4)));
-        PEM_TRY(T->vals.reserve(sizeof(double) * (nnz + 1)));
+        PEM_TRY(T->vals.reserve((size_t)T->value_bytes * (nnz + 1)));
         PEM_TRY(T->rowcolidx.reserve(nnz + 16));
         DevBuf &head = ctx->tmp[0];
         PEM_TRY(head.reserve(sizeof(int) * (nnz + 4)));
@@ -815,7 +857,7 @@ extern "C" pem_status pem_tiled_load(pem_ctx *ctx, const char *path, const pem_c
         }
         if (nnz) {
             PEM_HIP(hipMemcpyAsync(T->rowcolidx.p, payload.data() + L.off_rc, nnz, hipMemcpyHostToDevice, st));
-            PEM_HIP(hipMemcpyAsync(T->vals.p, payload.data() + L.off_vals, sizeof(double) * nnz, hipMemcpyHostToDevice, st));
+            PEM_HIP(hipMemcpyAsync(T->vals.p, payload.data() + L.off_vals, (size_t)T->value_bytes * nnz, hipMemcpyHostToDevice, st));
         }
         PEM_HIP(hipEventRecord(ctx->ev[6], st));
         lap("alloc + upload");
@@ -867,6 +909,8 @@ extern "C" pem_status pem_tiled_get_info(const pem_tiled *t, pem_tiled_info *inf
     info->ntiles = t->ntiles;
     info->conv_ms = t->conv_ms;
     info->conv_tile_kernel_ms = t->conv_tile_kernel_ms;
+    info->value_bytes = t->value_bytes;
+    info->reserved = 0;
     return PEM_OK;
 }
 
@@ -882,7 +926,7 @@ extern "C" pem_status pem_tiled_get_array(pem_ctx *ctx, const pem_tiled *t, pem_
     case PEM_T_MASKS: src = t->masks.p; want = 32 * T; break;
     case PEM_T_ROWPTR: src = t->rowptr.p; want = 16 * T; break;
     case PEM_T_ROWCOLIDX: src = t->rowcolidx.p; want = nnz; break;
-    case PEM_T_VALS: src = t->vals.p; want = 8 * nnz; break;
+    case PEM_T_VALS: src = t->vals.p; want = (size_t)t->value_bytes * nnz; break;   // native type: double or float
     case PEM_T_MASKS_T: src = t->masks_t.p; want = 32 * T; break;
     case PEM_T_TILE_ROWPTR: src = t->tile_rowptr.p; want = 4 * ((size_t)t->tile_rows + 1); break;
     case PEM_T_TILE_COLIDX: src = t->tile_colidx.p; want = 4 * T; break;

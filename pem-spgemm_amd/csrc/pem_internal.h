@@ -163,6 +163,7 @@ pem_status read_scalars(pem_ctx *ctx, const int64_t *d_src, int count, int64_t *
 }  // namespace pem
 
 struct pem_tiled {
+    int value_bytes = 8;              // 8: fp64 (the reference's ValueType, spgemm.cu:728), 4: fp32
     int rows = 0, cols = 0;
     int64_t nnz = 0;
     int tile_rows = 0, tile_cols = 0;

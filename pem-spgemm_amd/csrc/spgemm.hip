@@ -798,11 +798,17 @@ __global__ void __launch_bounds__(256) s2_crowcol_kernel(const uint16_t *__restr
 // accumulator lives in a register and is stored once (no global RMW, no dependence on
 // zero-filled memory -- SURVEY 2.3 #1).
 // ------------------------------------------------------------------------------------------
+// one fused multiply-add per product in the operands' own precision (the oracle's chain; the reference computes in
+// double, spgemm.cu:728 -- fp32 is SURVEY 8(f)-3)
+__device__ __forceinline__ double pem_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float pem_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+template <typename VT>
 __global__ void __launch_bounds__(256) s3_accumulate_kernel(
     const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b, long long ntc,
-    const int *__restrict__ c_tile_nnz_ptr, const uint8_t *__restrict__ c_rowcolidx, double *__restrict__ c_vals,
-    const int *__restrict__ a_nnz_ptr, const double *__restrict__ a_vals, const uint16_t *__restrict__ a_masks,
-    const uint8_t *__restrict__ a_rowptr, const int *__restrict__ b_nnz_ptr, const double *__restrict__ b_vals,
+    const int *__restrict__ c_tile_nnz_ptr, const uint8_t *__restrict__ c_rowcolidx, VT *__restrict__ c_vals,
+    const int *__restrict__ a_nnz_ptr, const VT *__restrict__ a_vals, const uint16_t *__restrict__ a_masks,
+    const uint8_t *__restrict__ a_rowptr, const int *__restrict__ b_nnz_ptr, const VT *__restrict__ b_vals,
     const uint16_t *__restrict__ b_masks, const uint8_t *__restrict__ b_rowptr, const uint16_t *__restrict__ b_masks_t)
 {
     long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -814,20 +820,20 @@ __global__ void __launch_bounds__(256) s3_accumulate_kernel(
         const unsigned rc = c_rowcolidx[off + n];
         const int r = rc >> 4, c = rc & 15;
         const unsigned clt = (1u << c) - 1u;
-        double acc = 0.0;
+        VT acc = VT(0);
         for (int p = p0; p < p1; ++p) {
             const int a = pairs_a[p], b = pairs_b[p];
             const unsigned am = a_masks[16 * (size_t)a + r];
             unsigned m = am & b_masks_t[16 * (size_t)b + c];
             if (!m) continue;
-            const double *av = a_vals + a_nnz_ptr[a] + a_rowptr[16 * (size_t)a + r];
-            const double *bvbase = b_vals + b_nnz_ptr[b];
+            const VT *av = a_vals + a_nnz_ptr[a] + a_rowptr[16 * (size_t)a + r];
+            const VT *bvbase = b_vals + b_nnz_ptr[b];
             while (m) {
                 const int kk = __builtin_ctz(m);
                 m &= m - 1;
                 const int ao = __popc(am & ((1u << kk) - 1u));
                 const int bo = __popc((unsigned)b_masks[16 * (size_t)b + kk] & clt);
-                acc = __builtin_fma(av[ao], bvbase[b_rowptr[16 * (size_t)b + kk] + bo], acc);
+                acc = pem_fma(av[ao], bvbase[b_rowptr[16 * (size_t)b + kk] + bo], acc);
             }
         }
         c_vals[off + n] = acc;
@@ -936,11 +942,12 @@ __global__ void __launch_bounds__(256) s2_crowcol_wide_kernel(const uint32_t *__
 // the two operand values.  Pairs ascend in k-tile, bits ascend, one fma per product: the same
 // chain as the oracle.
 constexpr int S3_EPW = 256;   // C entries per wave
+template <typename VT>
 __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b, long long ntc,
-    const int *__restrict__ c_tile_nnz_ptr, long long nnz_c, const uint8_t *__restrict__ c_rowcolidx, double *__restrict__ c_vals,
-    const int *__restrict__ a_nnz_ptr, const double *__restrict__ a_vals, const uint32_t *__restrict__ a_rec,
-    const int *__restrict__ b_nnz_ptr, const double *__restrict__ b_vals_t, const uint32_t *__restrict__ b_rec_t)
+    const int *__restrict__ c_tile_nnz_ptr, long long nnz_c, const uint8_t *__restrict__ c_rowcolidx, VT *__restrict__ c_vals,
+    const int *__restrict__ a_nnz_ptr, const VT *__restrict__ a_vals, const uint32_t *__restrict__ a_rec,
+    const int *__restrict__ b_nnz_ptr, const VT *__restrict__ b_vals_t, const uint32_t *__restrict__ b_rec_t)
 {
     // Work is dealt by ENTRIES, S3_EPW per wave, so hub rows (tiles with many entries and pairs) cannot pile
     // up in one wave.  The wave finds its first tile with a 64-ary search (one gather + ballot per level),
@@ -989,7 +996,7 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
         if (!valid) continue;
         const unsigned rc = c_rowcolidx[e];
         const int r = rc >> 4, c = rc & 15;
-        double acc = 0.0;
+        VT acc = VT(0);
         for (int p = p0; p < p1; ++p) {
             const int a = pairs_a[p], b = pairs_b[p];
             const unsigned aw = a_rec[16 * (size_t)a + r];
@@ -1000,13 +1007,13 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
             const unsigned bm = bw & 0xFFFFu;
             unsigned m = am & bm;
             if (!m) continue;
-            const double *av = a_vals + a_nnz_ptr[a] + (aw >> 16);
-            const double *bv = b_vals_t + b_nnz_ptr[b] + (bw >> 16);
+            const VT *av = a_vals + a_nnz_ptr[a] + (aw >> 16);
+            const VT *bv = b_vals_t + b_nnz_ptr[b] + (bw >> 16);
             while (m) {
                 const int kk = __builtin_ctz(m);
                 m &= m - 1;
                 const unsigned below = (1u << kk) - 1u;
-                acc = __builtin_fma(av[__popc(am & below)], bv[__popc(bm & below)], acc);
+                acc = pem_fma(av[__popc(am & below)], bv[__popc(bm & below)], acc);
             }
         }
         c_vals[e] = acc;
@@ -1033,11 +1040,12 @@ __global__ void __launch_bounds__(256) ex_rowcount_kernel(const int *__restrict_
     if (row < nrows) rowcnt[row] = cnt;
 }
 
+template <typename VT>
 __global__ void __launch_bounds__(256) ex_fill_kernel(const int *__restrict__ c_tile_rowptr, const int *__restrict__ c_tile_colidx,
                                                       const uint16_t *__restrict__ c_mask16, const int *__restrict__ c_tile_nnz_ptr,
-                                                      const uint8_t *__restrict__ c_rowptr, const double *__restrict__ c_vals, int mt,
+                                                      const uint8_t *__restrict__ c_rowptr, const VT *__restrict__ c_vals, int mt,
                                                       int nrows, const int *__restrict__ rowptr, int *__restrict__ colidx,
-                                                      double *__restrict__ vals)
+                                                      VT *__restrict__ vals)
 {
     int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     int r = threadIdx.x & 15;
@@ -1145,11 +1153,12 @@ __global__ void __launch_bounds__(256) ex_chunkscan_kernel(const int *__restrict
     if (16 * i + r < nrows) rowcnt[16 * i + r] = run;
 }
 
+template <typename VT>
 __global__ void __launch_bounds__(256) ex_chunkfill_kernel(const int *__restrict__ chunkptr, int mt, int nrows, const int *__restrict__ c_tile_rowptr,
                                                            const int *__restrict__ c_tile_colidx, const uint32_t *__restrict__ c_mask,
-                                                           const int *__restrict__ c_tile_nnz_ptr, const double *__restrict__ c_vals,
+                                                           const int *__restrict__ c_tile_nnz_ptr, const VT *__restrict__ c_vals,
                                                            const int *__restrict__ chunkbase, const int *__restrict__ rowptr,
-                                                           int *__restrict__ colidx, double *__restrict__ vals)
+                                                           int *__restrict__ colidx, VT *__restrict__ vals)
 {
     const int lane = threadIdx.x & 63;
     const int ch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1232,6 +1241,11 @@ extern "C" pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const p
     *out = nullptr;
     if (A->cols != B->rows) {
         set_error("pem_cplan_create: A is %d x %d but B is %d x %d", A->rows, A->cols, B->rows, B->cols);
+        return PEM_E_INVALID;
+    }
+    if (A->value_bytes != B->value_bytes) {
+        set_error("pem_cplan_create: A holds %s values, B %s; both operands must share one value type", A->value_bytes == 4 ? "fp32" : "fp64",
+                  B->value_bytes == 4 ? "fp32" : "fp64");
         return PEM_E_INVALID;
     }
     if (tr_hi < 0) tr_hi = A->tile_rows;
@@ -1601,7 +1615,7 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
     }
     p->nnz_c = nnzc;
     PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
-    PEM_TRY(p->c_vals.reserve(sizeof(double) * ((size_t)nnzc + 1)));
+    PEM_TRY(p->c_vals.reserve((size_t)A->value_bytes * ((size_t)nnzc + 1)));
     if (ntc > 0) {
         if (wide)
             PEM_LAUNCH(ctx, s2_crowcol_wide_kernel, grid_for(ntc, 256), 256, p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
@@ -1627,16 +1641,25 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
     if (!ctx->chain_events) PEM_HIP(hipEventRecord(ctx->ev[4], st));
     const char *wide_env = getenv("PEM_WIDE");
     const bool wide = !(wide_env && !strcmp(wide_env, "0"));
-    if (ntc > 0 && wide)
-        PEM_LAUNCH(ctx, s3_accumulate_wide_kernel, grid_for(((size_t)p->nnz_c + S3_EPW - 1) / S3_EPW * 64, 256), 256, p->pairs_offset.as<int>(),
-                   p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(), (long long)p->nnz_c,
-                   p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<double>(), A->tile_nnz_ptr.as<int>(),
-                   A->vals.as<double>(), A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<double>(), B->tile_rec_t.as<uint32_t>());
+    const bool f32 = A->value_bytes == 4;
+#define PEM_S3_LAUNCH(VT)                                                                                                                      \
+    do {                                                                                                                                       \
+        if (wide)                                                                                                                              \
+            PEM_LAUNCH(ctx, s3_accumulate_wide_kernel<VT>, grid_for(((size_t)p->nnz_c + S3_EPW - 1) / S3_EPW * 64, 256), 256,                  \
+                       p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),     \
+                       (long long)p->nnz_c, p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),     \
+                       A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>());               \
+        else                                                                                                                                   \
+            PEM_LAUNCH(ctx, s3_accumulate_kernel<VT>, grid_for(ntc * 16, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(),           \
+                       p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(),    \
+                       A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(), A->masks.as<uint16_t>(), A->rowptr.as<uint8_t>(),                          \
+                       B->tile_nnz_ptr.as<int>(), B->vals.as<VT>(), B->masks.as<uint16_t>(), B->rowptr.as<uint8_t>(), B->masks_t.as<uint16_t>()); \
+    } while (0)
+    if (ntc > 0 && f32)
+        PEM_S3_LAUNCH(float);
     else if (ntc > 0)
-        PEM_LAUNCH(ctx, s3_accumulate_kernel, grid_for(ntc * 16, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
-                   (long long)ntc, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<double>(), A->tile_nnz_ptr.as<int>(),
-                   A->vals.as<double>(), A->masks.as<uint16_t>(), A->rowptr.as<uint8_t>(), B->tile_nnz_ptr.as<int>(), B->vals.as<double>(),
-                   B->masks.as<uint16_t>(), B->rowptr.as<uint8_t>(), B->masks_t.as<uint16_t>());
+        PEM_S3_LAUNCH(double);
+#undef PEM_S3_LAUNCH
     PEM_HIP(hipEventRecord(ctx->ev[5], st));
     p->state = 3;
     return PEM_OK;
@@ -1726,7 +1749,7 @@ extern "C" pem_status pem_cplan_get_array(pem_ctx *ctx, const pem_cplan *p, pem_
     case PEM_C_TILE_NNZ_PTR: src = p->c_tile_nnz_ptr.p; want = 4 * (TC + 1); need = 2; break;
     case PEM_C_ROWPTR: src = p->c_rowptr.p; want = 16 * TC; need = 2; break;
     case PEM_C_ROWCOLIDX: src = p->c_rowcolidx.p; want = NZ; need = 2; break;
-    case PEM_C_VALS: src = p->c_vals.p; want = 8 * NZ; need = 3; break;
+    case PEM_C_VALS: src = p->c_vals.p; want = (size_t)p->A->value_bytes * NZ; need = 3; break;   // native type
     default: set_error("unknown pem_cplan_array %d", (int)which); return PEM_E_INVALID;
     }
     if (p->state < need) {
@@ -1744,13 +1767,24 @@ extern "C" pem_status pem_cplan_get_array(pem_ctx *ctx, const pem_cplan *p, pem_
     return PEM_OK;
 }
 
-extern "C" pem_status pem_c_export_csr_device(pem_ctx *ctx, const pem_cplan *p, int32_t *d_rowptr, int32_t *d_colidx, double *d_vals)
+// the plan's value type is A's (checked equal to B's at plan creation)
+static bool export_type_ok(const pem_cplan *p, int value_bytes, const char *fn)
+{
+    if (p->A->value_bytes == value_bytes) return true;
+    set_error("%s: the plan holds %s values; use the %s export entry points", fn, p->A->value_bytes == 4 ? "fp32" : "fp64",
+              p->A->value_bytes == 4 ? "_f32" : "fp64");
+    return false;
+}
+
+template <typename VT>
+static pem_status export_csr_device_impl(pem_ctx *ctx, const pem_cplan *p, int32_t *d_rowptr, int32_t *d_colidx, VT *d_vals)
 {
     if (!ctx || !p || !d_rowptr) return PEM_E_INVALID;
     if (p->state < 3) {
         set_error("pem_c_export_csr: step 3 has not run");
         return PEM_E_STATE;
     }
+    if (!export_type_ok(p, (int)sizeof(VT), "pem_c_export_csr")) return PEM_E_INVALID;
     if (p->nnz_c > 0 && (!d_colidx || !d_vals)) return PEM_E_INVALID;
     PEM_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -1765,8 +1799,8 @@ extern "C" pem_status pem_c_export_csr_device(pem_ctx *ctx, const pem_cplan *p, 
                    d_rowptr);
         PEM_TRY(exclusive_scan_i32(ctx, d_rowptr, d_rowptr, (size_t)nrows, nullptr));
         if (p->nnz_c > 0)
-            PEM_LAUNCH(ctx, ex_fill_kernel, grid_for((size_t)mt * 16, 256), 256, p->c_tile_rowptr.as<int>(), p->c_tile_colidx.as<int>(),
-                       p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>(), p->c_rowptr.as<uint8_t>(), p->c_vals.as<double>(), mt, nrows,
+            PEM_LAUNCH(ctx, ex_fill_kernel<VT>, grid_for((size_t)mt * 16, 256), 256, p->c_tile_rowptr.as<int>(), p->c_tile_colidx.as<int>(),
+                       p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>(), p->c_rowptr.as<uint8_t>(), p->c_vals.as<VT>(), mt, nrows,
                        d_rowptr, d_colidx, d_vals);
     } else if (mt > 0 && nrows > 0) {
         const size_t maxchunks = (size_t)p->ntiles_c / 64 + (size_t)mt + 1;   // every tile row adds at most one partial chunk
@@ -1781,15 +1815,16 @@ extern "C" pem_status pem_c_export_csr_device(pem_ctx *ctx, const pem_cplan *p, 
         PEM_LAUNCH(ctx, ex_chunkscan_kernel, grid_for((size_t)mt * 16, 256), 256, chunkptr.as<int>(), mt, nrows, chunkhist.as<int>(), d_rowptr);
         PEM_TRY(exclusive_scan_i32(ctx, d_rowptr, d_rowptr, (size_t)nrows, nullptr));
         if (p->nnz_c > 0)
-            PEM_LAUNCH(ctx, ex_chunkfill_kernel, grid_for(maxchunks * 64, 256), 256, chunkptr.as<int>(), mt, nrows, p->c_tile_rowptr.as<int>(),
-                       p->c_tile_colidx.as<int>(), p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>(), p->c_vals.as<double>(), chunkhist.as<int>(),
+            PEM_LAUNCH(ctx, ex_chunkfill_kernel<VT>, grid_for(maxchunks * 64, 256), 256, chunkptr.as<int>(), mt, nrows, p->c_tile_rowptr.as<int>(),
+                       p->c_tile_colidx.as<int>(), p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>(), p->c_vals.as<VT>(), chunkhist.as<int>(),
                        d_rowptr, d_colidx, d_vals);
     }
     PEM_HIP(hipEventRecord(ctx->ev[7], st));
     return PEM_OK;
 }
 
-extern "C" pem_status pem_c_export_csr(pem_ctx *ctx, const pem_cplan *p, int64_t *nnz, int32_t *rowptr, int32_t *colidx, double *vals)
+template <typename VT>
+static pem_status export_csr_impl(pem_ctx *ctx, const pem_cplan *p, int64_t *nnz, int32_t *rowptr, int32_t *colidx, VT *vals)
 {
     if (!ctx || !p) return PEM_E_INVALID;
     if (p->state < 3) {
@@ -1798,19 +1833,20 @@ extern "C" pem_status pem_c_export_csr(pem_ctx *ctx, const pem_cplan *p, int64_t
     }
     if (nnz) *nnz = p->nnz_c;
     if (!rowptr) return PEM_OK;   // size query
+    if (!export_type_ok(p, (int)sizeof(VT), "pem_c_export_csr")) return PEM_E_INVALID;
     PEM_HIP(hipSetDevice(ctx->device));
     const int r0 = p->tr_lo * 16, r1 = p->tr_hi * 16 < p->A->rows ? p->tr_hi * 16 : p->A->rows;
     const size_t nrows = (size_t)(r1 - r0), nz = (size_t)p->nnz_c;
     DevBuf dR, dC, dV;
     PEM_TRY(dR.reserve(sizeof(int) * (nrows + 4)));
     PEM_TRY(dC.reserve(sizeof(int) * (nz + 4)));
-    PEM_TRY(dV.reserve(sizeof(double) * (nz + 1)));
-    PEM_TRY(pem_c_export_csr_device(ctx, p, dR.as<int>(), dC.as<int>(), dV.as<double>()));
+    PEM_TRY(dV.reserve(sizeof(VT) * (nz + 1)));
+    PEM_TRY(export_csr_device_impl<VT>(ctx, p, dR.as<int>(), dC.as<int>(), dV.as<VT>()));
     PEM_HIP(hipMemcpyAsync(rowptr, dR.p, sizeof(int) * (nrows + 1), hipMemcpyDeviceToHost, ctx->stream));
     if (nz) {
         if (!colidx || !vals) return PEM_E_INVALID;
         PEM_HIP(hipMemcpyAsync(colidx, dC.p, sizeof(int) * nz, hipMemcpyDeviceToHost, ctx->stream));
-        PEM_HIP(hipMemcpyAsync(vals, dV.p, sizeof(double) * nz, hipMemcpyDeviceToHost, ctx->stream));
+        PEM_HIP(hipMemcpyAsync(vals, dV.p, sizeof(VT) * nz, hipMemcpyDeviceToHost, ctx->stream));
     }
     PEM_HIP(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
@@ -1818,7 +1854,8 @@ extern "C" pem_status pem_c_export_csr(pem_ctx *ctx, const pem_cplan *p, int64_t
     return PEM_OK;
 }
 
-extern "C" pem_status pem_c_export_coo(pem_ctx *ctx, const pem_cplan *p, int64_t *nnz, int32_t *rows, int32_t *cols, double *vals)
+template <typename VT>
+static pem_status export_coo_impl(pem_ctx *ctx, const pem_cplan *p, int64_t *nnz, int32_t *rows, int32_t *cols, VT *vals)
 {
     if (!ctx || !p) return PEM_E_INVALID;
     if (p->state < 3) {
@@ -1829,10 +1866,35 @@ extern "C" pem_status pem_c_export_coo(pem_ctx *ctx, const pem_cplan *p, int64_t
     if (!rows) return PEM_OK;
     const int r0 = p->tr_lo * 16, r1 = p->tr_hi * 16 < p->A->rows ? p->tr_hi * 16 : p->A->rows;
     std::vector<int> rp((size_t)(r1 - r0) + 1);
-    PEM_TRY(pem_c_export_csr(ctx, p, nullptr, rp.data(), cols, vals));
+    PEM_TRY(export_csr_impl<VT>(ctx, p, nullptr, rp.data(), cols, vals));
     for (int r = r0; r < r1; ++r)   // sorted (row, col) order = CSR order (spgemm.cu:1516-1519)
         for (int e = rp[(size_t)(r - r0)]; e < rp[(size_t)(r - r0) + 1]; ++e) rows[e] = r;
     return PEM_OK;
+}
+
+extern "C" pem_status pem_c_export_csr_device(pem_ctx *ctx, const pem_cplan *p, int32_t *d_rowptr, int32_t *d_colidx, double *d_vals)
+{
+    return export_csr_device_impl<double>(ctx, p, d_rowptr, d_colidx, d_vals);
+}
+extern "C" pem_status pem_c_export_csr_device_f32(pem_ctx *ctx, const pem_cplan *p, int32_t *d_rowptr, int32_t *d_colidx, float *d_vals)
+{
+    return export_csr_device_impl<float>(ctx, p, d_rowptr, d_colidx, d_vals);
+}
+extern "C" pem_status pem_c_export_csr(pem_ctx *ctx, const pem_cplan *p, int64_t *nnz, int32_t *rowptr, int32_t *colidx, double *vals)
+{
+    return export_csr_impl<double>(ctx, p, nnz, rowptr, colidx, vals);
+}
+extern "C" pem_status pem_c_export_csr_f32(pem_ctx *ctx, const pem_cplan *p, int64_t *nnz, int32_t *rowptr, int32_t *colidx, float *vals)
+{
+    return export_csr_impl<float>(ctx, p, nnz, rowptr, colidx, vals);
+}
+extern "C" pem_status pem_c_export_coo(pem_ctx *ctx, const pem_cplan *p, int64_t *nnz, int32_t *rows, int32_t *cols, double *vals)
+{
+    return export_coo_impl<double>(ctx, p, nnz, rows, cols, vals);
+}
+extern "C" pem_status pem_c_export_coo_f32(pem_ctx *ctx, const pem_cplan *p, int64_t *nnz, int32_t *rows, int32_t *cols, float *vals)
+{
+    return export_coo_impl<float>(ctx, p, nnz, rows, cols, vals);
 }
 
 extern "C" pem_status pem_split_tile_rows(pem_ctx *ctx, const pem_tiled *A, const pem_tiled *B, int nparts, int32_t *bounds)

@@ -37,13 +37,16 @@ int main(int argc, char *argv[])
     // `--out <file.mtx>` writes C as a Matrix-Market file.  They are stripped before the reference's own grammar.
     // `--cache <dir>` keeps each tiling as <dir>/<stem>.<A|AT>.pemtile and, while the .mtx is unchanged
     // (size + mtime), loads it instead of parsing and converting.
+    // `--fp32` computes in float: the values are rounded once at conversion, step 3 runs one fmaf per product.
     const char *b_path = nullptr, *out_path = nullptr, *cache_dir = nullptr;
+    bool fp32 = false;
     {
         int w = 1;
         for (int r = 1; r < argc; ++r) {
             if (!strcmp(argv[r], "--B") && r + 1 < argc) b_path = argv[++r];
             else if (!strcmp(argv[r], "--out") && r + 1 < argc) out_path = argv[++r];
             else if (!strcmp(argv[r], "--cache") && r + 1 < argc) cache_dir = argv[++r];
+            else if (!strcmp(argv[r], "--fp32")) fp32 = true;
             else argv[w++] = argv[r];
         }
         argc = w;
@@ -87,11 +90,17 @@ int main(int argc, char *argv[])
                 std::string p = src.path;
                 size_t sl = p.find_last_of('/');
                 std::string stem = sl == std::string::npos ? p : p.substr(sl + 1);
-                cpath = std::string(cache_dir) + "/" + stem + (transpose ? ".AT" : ".A") + ".pemtile";
+                cpath = std::string(cache_dir) + "/" + stem + (transpose ? ".AT" : ".A") + (fp32 ? ".f32" : "") + ".pemtile";
                 pem_status ls = pem_tiled_load(ctx, cpath.c_str(), &key, out);
                 if (ls == PEM_OK) {
-                    ++cache_hits;
-                    return 0;
+                    pem_tiled_info li;
+                    if (pem_tiled_get_info(*out, &li) == PEM_OK && li.value_bytes == (fp32 ? 4 : 8)) {
+                        ++cache_hits;
+                        return 0;
+                    }
+                    pem_tiled_destroy(ctx, *out);   // a file of the other value type under this name: rebuild
+                    *out = nullptr;
+                    ls = PEM_E_STALE;
                 }
                 if (ls != PEM_E_IO && ls != PEM_E_STALE) {
                     fprintf(stderr, "pemspgemm: %s\n", pem_last_error());
@@ -108,7 +117,15 @@ int main(int argc, char *argv[])
             src.read = true;
         }
         const pem_coo &m = src.coo;
-        if (pem_tiled_from_coo(ctx, m.rows, m.cols, m.nnz, m.I, m.J, m.V, transpose, out) != PEM_OK) {
+        pem_status cs;
+        if (fp32) {
+            std::vector<float> vf((size_t)m.nnz);
+            for (int64_t e = 0; e < m.nnz; ++e) vf[(size_t)e] = (float)m.V[e];
+            cs = pem_tiled_from_coo_f32(ctx, m.rows, m.cols, m.nnz, m.I, m.J, vf.data(), transpose, out);
+        } else {
+            cs = pem_tiled_from_coo(ctx, m.rows, m.cols, m.nnz, m.I, m.J, m.V, transpose, out);
+        }
+        if (cs != PEM_OK) {
             fprintf(stderr, "pemspgemm: conversion of %s failed: %s\n", src.path, pem_last_error());
             return 2;
         }
@@ -135,6 +152,7 @@ int main(int argc, char *argv[])
             printf("input is rectangular. Only AAt is possible. Exiting.\n");   // spgemm.cu:782-786
         return 1;
     }
+    if (fp32) printf("value type: fp32 (the reference computes in fp64)\n");
     printf("MATRIX A\nfilepath: %s\nRows: %d\nCols: %d\nNnz: %lld\n", argv[1], ia.rows, ia.cols, (long long)ia.nnz);   // spgemm.cu:794-806
     printf("MATRIX B\nfilepath: %s\nRows: %d\nCols: %d\nNnz: %lld\n", b_path ? b_path : argv[1], ib.rows, ib.cols, (long long)ib.nnz);
     if (cache_dir) printf("tiled-format cache %s: %d loaded, %d rebuilt\n", cache_dir, cache_hits, cache_misses);
@@ -216,7 +234,13 @@ int main(int argc, char *argv[])
         std::vector<int32_t> rows((size_t)ci.nnz_c), cols((size_t)ci.nnz_c);
         std::vector<double> vals((size_t)ci.nnz_c);
         int64_t nnz = 0;
-        CHECK(pem_c_export_coo(ctx, plan, &nnz, rows.data(), cols.data(), vals.data()));   // spgemm.cu:1493-1543
+        if (fp32) {
+            std::vector<float> vf((size_t)ci.nnz_c);
+            CHECK(pem_c_export_coo_f32(ctx, plan, &nnz, rows.data(), cols.data(), vf.data()));
+            for (size_t e = 0; e < vf.size(); ++e) vals[e] = vf[e];
+        } else {
+            CHECK(pem_c_export_coo(ctx, plan, &nnz, rows.data(), cols.data(), vals.data()));   // spgemm.cu:1493-1543
+        }
         pem_timings t;
         CHECK(pem_get_timings(ctx, &t));
         printf("sanitize_C took %.2fms\n", t.export_ms);
@@ -230,7 +254,13 @@ int main(int argc, char *argv[])
         std::vector<int32_t> rp((size_t)(ci.row_end - ci.row_begin) + 1), cidx((size_t)ci.nnz_c);
         std::vector<double> cv((size_t)ci.nnz_c);
         int64_t nnz = 0;
-        CHECK(pem_c_export_csr(ctx, plan, &nnz, rp.data(), cidx.data(), cv.data()));
+        if (fp32) {
+            std::vector<float> vf((size_t)ci.nnz_c);
+            CHECK(pem_c_export_csr_f32(ctx, plan, &nnz, rp.data(), cidx.data(), vf.data()));
+            for (size_t e = 0; e < vf.size(); ++e) cv[e] = vf[e];
+        } else {
+            CHECK(pem_c_export_csr(ctx, plan, &nnz, rp.data(), cidx.data(), cv.data()));
+        }
         if (pem_write_mtx_csr(out_path, ia.rows, ib.cols, rp.data(), cidx.data(), cv.data(), "C = A*B by pemspgemm (pem-spgemm_amd)") != 0) {
             fprintf(stderr, "pemspgemm: %s\n", pem_host_last_error());
             rc = 2;

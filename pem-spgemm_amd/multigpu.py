@@ -19,7 +19,7 @@ def slice_bounds(bounds, rank):
 def gather_csr_slices(rowptr, colidx, vals, dst=0, group=None):
     """Gather per-rank CSR row slices (rowptr relative, starting at 0) into one CSR on `dst`.
 
-    rowptr: int32 [nrows_r + 1], colidx: int32 [nnz_r], vals: float64 [nnz_r] on this rank.
+    rowptr: int32 [nrows_r + 1], colidx: int32 [nnz_r], vals: float64 (float32 for fp32 tilings) [nnz_r] on this rank.
     Returns (rowptr, colidx, vals) of the whole C on `dst`, None elsewhere.  Slices are
     concatenated in rank order, so with tile-row-aligned splits the result equals the 1-GPU
     CSR bit for bit (structure and values).
@@ -44,7 +44,7 @@ def gather_csr_slices(rowptr, colidx, vals, dst=0, group=None):
     tot_rows, tot_nnz = sum(nrows), sum(nnzs)
     out_rp = torch.zeros(tot_rows + 1, dtype=torch.int32, device=dev)
     out_ci = torch.empty(tot_nnz, dtype=torch.int32, device=dev)
-    out_v = torch.empty(tot_nnz, dtype=torch.float64, device=dev)
+    out_v = torch.empty(tot_nnz, dtype=vals.dtype, device=dev)   # float64, or float32 for fp32 tilings
     rp_parts = [None] * world
     ops = []
     roff = noff = 0

@@ -41,11 +41,11 @@ def _pad64(b):
     return b + b"\0" * ((-len(b)) % 64)
 
 
-def payload_bytes(tile_keys, tile_nnz_ptr, rowcolidx, vals):
+def payload_bytes(tile_keys, tile_nnz_ptr, rowcolidx, vals, value_bytes=8):
     return (_pad64(np.ascontiguousarray(tile_keys, dtype="<i8").tobytes()) +
             _pad64(np.ascontiguousarray(tile_nnz_ptr, dtype="<i4").tobytes()) +
             _pad64(np.ascontiguousarray(rowcolidx, dtype=np.uint8).tobytes()) +
-            _pad64(np.ascontiguousarray(vals, dtype="<f8").tobytes()))
+            _pad64(np.ascontiguousarray(vals, dtype="<f8" if value_bytes == 8 else "<f4").tobytes()))
 
 
 def header_bytes(rows, cols, nnz, ntiles, payload, key=(0, 0, 0), version=1, tile=16, value_bytes=8, payload_hash=None):
@@ -55,17 +55,18 @@ def header_bytes(rows, cols, nnz, ntiles, payload, key=(0, 0, 0), version=1, til
     return HEADER.pack(*fields, hash64(h0, SEED_HEADER))
 
 
-def cache_bytes(rows, cols, tile_keys, tile_nnz_ptr, rowcolidx, vals, key=(0, 0, 0), nnz=None, ntiles=None):
-    p = payload_bytes(tile_keys, tile_nnz_ptr, rowcolidx, vals)
+def cache_bytes(rows, cols, tile_keys, tile_nnz_ptr, rowcolidx, vals, key=(0, 0, 0), nnz=None, ntiles=None, value_bytes=8):
+    """value_bytes 8: fp64 (the reference's ValueType); 4: fp32 tilings."""
+    p = payload_bytes(tile_keys, tile_nnz_ptr, rowcolidx, vals, value_bytes)
     nnz = len(vals) if nnz is None else nnz
     ntiles = len(tile_keys) if ntiles is None else ntiles
-    return header_bytes(rows, cols, nnz, ntiles, p, key) + p
+    return header_bytes(rows, cols, nnz, ntiles, p, key, value_bytes=value_bytes) + p
 
 
 def read_cache(path):
     raw = open(path, "rb").read()
     (magic, version, tile, vbytes, hbytes, rows, cols, nnz, ntiles, ksize, kmtime, ktr, _res, pbytes, phash, hhash) = HEADER.unpack(raw[:128])
-    assert magic == MAGIC and version == 1 and tile == 16 and vbytes == 8 and hbytes == 128
+    assert magic == MAGIC and version == 1 and tile == 16 and vbytes in (4, 8) and hbytes == 128
     z = bytearray(raw[:128])
     z[88:96] = b"\0" * 8
     assert hash64(bytes(z), SEED_HEADER) == hhash, "header checksum"
@@ -83,6 +84,7 @@ def read_cache(path):
     out["tile_keys"] = take(ntiles, "<i8")
     out["tile_nnz_ptr"] = take(ntiles + 1, "<i4")
     out["rowcolidx"] = take(nnz, np.uint8)
-    out["vals"] = take(nnz, "<f8")
+    out["vals"] = take(nnz, "<f8" if vbytes == 8 else "<f4")
+    out["value_bytes"] = vbytes
     assert off == len(payload)
     return out
