@@ -61,6 +61,12 @@ def main():
     ap.add_argument("--aat", action="store_true", help="C = A*A^T instead of A^2 (default for mc2depi)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
                     help="value type: f64 = the reference's ValueType and BASELINE's metric; f32 = SURVEY 8(f)-3 (not the headline)")
+    ap.add_argument("--grid", default=None, metavar="RxC",
+                    help="N>1: 2-D partition (SURVEY 8(f)-4), R row blocks of A x C column blocks of B, R*C = --gpus; each rank "
+                         "holds only its rows of A and its columns of B.  Default: 1-D row blocks, B replicated (the BASELINE configs)")
+    ap.add_argument("--chunks", type=int, default=0, metavar="K",
+                    help="N>1, 1-D: also time the pipelined form -- each rank's row block in K chunks, chunk c's CSR travelling "
+                         "to rank 0 while chunk c+1 computes (SURVEY 8(f)-4); reported as exchange.pipelined")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave the C slices on their ranks")
     args = ap.parse_args()
@@ -104,15 +110,42 @@ def main():
     np_dt, torch_dt, vbytes = (np.float32, torch.float32, 4) if args.dtype == "f32" else (np.float64, torch.float64, 8)
     if args.dtype == "f32":
         V = V.astype(np.float32)
-    dI, dJ, dV = torch.from_numpy(I).to(dev), torch.from_numpy(J).to(dev), torch.from_numpy(V).to(dev)
-    torch.cuda.synchronize()
     ctx = pkg.Context(dev_index)
-    A = pkg.Tiled.from_coo_device(ctx, rows, cols, len(I), dI.data_ptr(), dJ.data_ptr(), dV.data_ptr(), False, dtype=np_dt)
-    B = pkg.Tiled.from_coo_device(ctx, rows, cols, len(I), dI.data_ptr(), dJ.data_ptr(), dV.data_ptr(), True, dtype=np_dt) if aat else A
-    del dI, dJ, dV
-    flop = pkg.flop_count(ctx, A, B)
-    bounds = pkg.split_tile_rows(ctx, A, B, world)
-    lo, hi = mg.slice_bounds(bounds, rank)
+    grid = None
+    if args.grid:
+        nrb, ncb = (int(x) for x in args.grid.lower().split("x"))
+        if nrb * ncb != world:
+            if rank == 0:
+                print(f"bench.py: --grid {args.grid} needs {nrb * ncb} ranks, got {world}", file=sys.stderr)
+            sys.exit(2)
+        grid = (nrb, ncb)
+    if grid is None:
+        dI, dJ, dV = torch.from_numpy(I).to(dev), torch.from_numpy(J).to(dev), torch.from_numpy(V).to(dev)
+        torch.cuda.synchronize()
+        A = pkg.Tiled.from_coo_device(ctx, rows, cols, len(I), dI.data_ptr(), dJ.data_ptr(), dV.data_ptr(), False, dtype=np_dt)
+        B = pkg.Tiled.from_coo_device(ctx, rows, cols, len(I), dI.data_ptr(), dJ.data_ptr(), dV.data_ptr(), True, dtype=np_dt) if aat else A
+        del dI, dJ, dV
+        flop = pkg.flop_count(ctx, A, B)
+        bounds = pkg.split_tile_rows(ctx, A, B, world)
+        lo, hi = mg.slice_bounds(bounds, rank)
+    else:
+        # rank (i, j) uploads and tiles only rows block i of A and columns block j of B
+        BI, BJ = (J, I) if aat else (I, J)
+        brows, bcols = (cols, rows) if aat else (rows, cols)
+        rb = mg.balanced_tile_bounds(I, rows, grid[0])
+        cb = mg.balanced_tile_bounds(BJ, bcols, grid[1])
+        gi, gj = mg.grid_coords(rank, grid[1])
+        ma, mb = mg.restrict(I, rb[gi], rb[gi + 1]), mg.restrict(BJ, cb[gj], cb[gj + 1])
+        dA = [torch.from_numpy(np.ascontiguousarray(x[ma])).to(dev) for x in (I, J, V)]
+        dB = [torch.from_numpy(np.ascontiguousarray(x[mb])).to(dev) for x in (BI, BJ, V)]
+        torch.cuda.synchronize()
+        A = pkg.Tiled.from_coo_device(ctx, rows, cols, int(ma.sum()), dA[0].data_ptr(), dA[1].data_ptr(), dA[2].data_ptr(), False, dtype=np_dt)
+        B = pkg.Tiled.from_coo_device(ctx, brows, bcols, int(mb.sum()), dB[0].data_ptr(), dB[1].data_ptr(), dB[2].data_ptr(), False, dtype=np_dt)
+        del dA, dB
+        ft = torch.tensor([pkg.flop_count(ctx, A, B)], dtype=torch.int64, device=dev)   # every product lies in exactly one block
+        dist.all_reduce(ft)
+        flop = int(ft.item())
+        lo, hi = rb[gi], rb[gi + 1]
     plan = pkg.CPlan(ctx, A, B, lo, hi)
 
     gather = world > 1 and not args.no_gather
@@ -132,7 +165,10 @@ def main():
                         v=torch.empty(max(nz, 1), dtype=torch_dt, device=dev))
         plan.export_csr_device(bufs["rp"].data_ptr(), bufs["ci"].data_ptr(), bufs["v"].data_ptr())
         ctx.synchronize()
-        bufs["out"] = mg.gather_csr_slices(bufs["rp"], bufs["ci"][:nz], bufs["v"][:nz], dst=0)
+        if grid is None:
+            bufs["out"] = mg.gather_csr_slices(bufs["rp"], bufs["ci"][:nz], bufs["v"][:nz], dst=0)
+        else:
+            bufs["out"] = mg.gather_csr_blocks(bufs["rp"], bufs["ci"][:nz], bufs["v"][:nz], grid[1], dst=0)
 
     def fence():
         if dist is not None:
@@ -157,11 +193,34 @@ def main():
         if gather:
             exchange()
     elapsed = timed(step, args.steps)
+    tm = ctx.timings()          # step spans of the last timed pass on this rank's plan
     # The metric times step1+2+3 (BASELINE.json); collecting the row blocks on one GPU is the path's exchange
     # step and is timed separately over the same K passes (it is bounded by the root's xGMI ingest, not compute).
     exchange_ms = timed(exchange, args.steps) * 1e3 / max(args.steps, 1) if gather else None
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
-    tm = ctx.timings()
+    pipelined = None
+    if gather and grid is None and args.chunks > 0:
+        cb = pkg.split_tile_rows(ctx, A, B, world * args.chunks)
+        crb = mg.ChunkedRowBlock(pkg, ctx, A, B, cb, rank, args.chunks, torch_dt, dst=0)
+        crb.run_pass()                                            # sizes + staging buffers; plans warm up
+        crb.run_pass()
+        t_pipe = timed(lambda: bufs.__setitem__("pipe_out", crb.run_pass()), args.steps) * 1e3 / max(args.steps, 1)
+        pipelined = {"chunks": args.chunks, "ms_per_step": t_pipe,
+                     "what": "steps 1-3 of every chunk + device CSR export + gather to rank 0, chunk c in flight while chunk c+1 computes",
+                     "sequential_ms_per_step": ms_per_step + exchange_ms,
+                     "value_with_exchange": 2.0 * flop / (t_pipe * 1e-3) / 1e9}
+        if rank == 0:
+            prp, pci, pv = bufs["pipe_out"]
+            pipelined["fingerprint"] = {"nnz": int(pci.numel()), "colidx_sum": int(pci.to(torch.int64).sum().item()),
+                                        "rowptr_sum": int(prp.to(torch.int64).sum().item()),
+                                        "vals_sum": float(pv.to(torch.float64).cpu().sum().item())}
+    gathered = None
+    if gather and rank == 0 and bufs.get("out") is not None:
+        # fingerprint of the assembled C on the root (tests compare it across partitionings; equal arrays give equal sums)
+        grp, gci, gv = bufs["out"]
+        gathered = {"rows": int(grp.numel() - 1), "nnz": int(gci.numel()), "rowptr_last": int(grp[-1].item()) if grp.numel() else 0,
+                    "colidx_sum": int(gci.to(torch.int64).sum().item()), "rowptr_sum": int(grp.to(torch.int64).sum().item()),
+                    "vals_sum": float(gv.to(torch.float64).cpu().sum().item()), "vals_abs_sum": float(gv.to(torch.float64).abs().cpu().sum().item())}
     info = plan.info()
 
     # per-kernel device time, measured live with HIP events on the library's stream (separate
@@ -237,7 +296,7 @@ def main():
             "config": {"workload": f"{args.workload} stand-in (seeded synthetic, scale {args.scale}) {'A*A^T' if aat else 'A^2'}",
                        "rows": rows, "cols": cols, "nnz": int(len(I)), "flop": int(flop), "C_nnz": total_nnz_c, "C_tiles": total_tc,
                        "tile_pairs": total_p, "A_tiles": int(A.ntiles), "compression_ratio": flop / max(total_nnz_c, 1),
-                       "parallelism": f"rowblock{world}" + ("+gather" if gather else "")},
+                       "parallelism": (f"rowblock{world}" if grid is None else f"grid{grid[0]}x{grid[1]}") + ("+gather" if gather else "")},
             "roofline": roofline,
             "roofline_pipeline": {"bound": "hbm", "B_alg_bytes": b_alg, "t_kernel_ms": t_kernel_ms,
                                   "achieved": b_alg / (t_kernel_ms * 1e-3) / 1e9 if t_kernel_ms > 0 else None, "peak": HBM_PEAK_GBS,
@@ -247,7 +306,8 @@ def main():
             "exchange": None if exchange_ms is None else {
                 "ms_per_step": exchange_ms, "what": "pem_c_export_csr_device + gather of the CSR row blocks to rank 0 (P2P over RCCL)",
                 "bytes_to_root": 12 * (total_nnz_c - info["nnz_c"]),
-                "value_with_exchange": 2.0 * flop / ((ms_per_step + exchange_ms) * 1e-3) / 1e9},
+                "value_with_exchange": 2.0 * flop / ((ms_per_step + exchange_ms) * 1e-3) / 1e9,
+                "gathered": gathered, "pipelined": pipelined},
             "steps_ms": {"step1": tm["step1_ms"], "step2": tm["step2_ms"], "step3": tm["step3_ms"], "wall_last": tm["spgemm_wall_ms"]},
             "conversion_ms": {"A": A.conv_ms, "A_tile_kernels": A.conv_tile_kernel_ms},
             "kernels": kern,

@@ -70,3 +70,230 @@ def gather_csr_slices(rowptr, colidx, vals, dst=0, group=None):
         ro, no = offs[r]
         out_rp[ro + 1:ro + nrows[r] + 1] = rp_parts[r][1:] + no
     return out_rp, out_ci, out_v
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# 2-D (row block of A) x (column block of B) partition, for inputs whose replicated B does not fit.
+# Rank (i, j) of an R x Cb grid holds only rows block i of A and columns block j of B (both cut from the COO before
+# upload, indices left global so tile ids of C are global) and computes the whole block C(i, j) = A(i, :) * B(:, j)
+# with no communication: every C entry still sees its full k range in ascending order, so values are bit-identical
+# to the 1-GPU result.  The blocks are gathered to one rank and spliced row by row (column blocks in order).
+# ------------------------------------------------------------------------------------------------------------------
+def grid_coords(rank, ncol_blocks):
+    """(row block, column block) of `rank` in a row-major R x Cb grid"""
+    return rank // ncol_blocks, rank % ncol_blocks
+
+
+def balanced_tile_bounds(index, extent, nparts):
+    """Boundaries (in tiles of 16) cutting [0, ceil(extent/16)) into `nparts` ranges of about equal nnz.
+    index: row (or column) index of every nonzero; returns nparts+1 ascending tile indices."""
+    import numpy as np
+    ntile = (int(extent) + 15) // 16
+    cnt = np.bincount(np.asarray(index, dtype=np.int64) >> 4, minlength=ntile).astype(np.int64)
+    pre = np.concatenate([[0], np.cumsum(cnt)])
+    bounds = [0]
+    for g in range(1, nparts):
+        target = pre[-1] * g / nparts
+        t = int(np.searchsorted(pre, target, side="left"))
+        bounds.append(min(max(t, bounds[-1]), ntile))
+    bounds.append(ntile)
+    return bounds
+
+
+def restrict(index, lo_tile, hi_tile):
+    """boolean mask of the nonzeros whose `index` (row or column) lies in tiles [lo_tile, hi_tile)"""
+    import numpy as np
+    index = np.asarray(index)
+    return (index >= 16 * lo_tile) & (index < 16 * hi_tile)
+
+
+def assemble_csr_blocks(blocks, ncol_blocks):
+    """Splice the CSR blocks of an R x Cb grid (row-major list of (rowptr, colidx, vals); rowptr relative to the
+    block's first row, column indices global and ascending across column blocks) into one CSR.
+    Works on any device; returns (rowptr int32, colidx int32, vals)."""
+    nrb = len(blocks) // ncol_blocks
+    dev = blocks[0][0].device
+    vdt = blocks[0][2].dtype
+    rp_parts, entries = [], []
+    row_base = 0
+    lens_all = []
+    for i in range(nrb):
+        row = blocks[i * ncol_blocks:(i + 1) * ncol_blocks]
+        nrows = row[0][0].numel() - 1
+        lens = torch.stack([(b[0][1:] - b[0][:-1]).to(torch.int64) for b in row])      # [Cb, nrows]
+        lens_all.append(lens)
+        row_base += nrows
+    tot_len = torch.cat([l.sum(0) for l in lens_all]) if lens_all else torch.zeros(0, dtype=torch.int64, device=dev)
+    out_rp = torch.zeros(tot_len.numel() + 1, dtype=torch.int64, device=dev)
+    out_rp[1:] = torch.cumsum(tot_len, 0)
+    nnz = int(out_rp[-1])
+    out_ci = torch.empty(nnz, dtype=torch.int32, device=dev)
+    out_v = torch.empty(nnz, dtype=vdt, device=dev)
+    row0 = 0
+    for i in range(nrb):
+        lens = lens_all[i]
+        nrows = lens.shape[1]
+        before = torch.cumsum(lens, 0) - lens                                            # entries of lower column blocks, per row
+        for j in range(ncol_blocks):
+            rp, ci, v = blocks[i * ncol_blocks + j]
+            if ci.numel() == 0:
+                continue
+            rows = torch.repeat_interleave(torch.arange(nrows, device=dev), lens[j])     # block-local row of every entry
+            within = torch.arange(ci.numel(), device=dev) - rp[:-1].to(torch.int64)[rows]
+            dst = out_rp[row0 + rows] + before[j][rows] + within
+            out_ci[dst] = ci
+            out_v[dst] = v
+        row0 += nrows
+    return out_rp.to(torch.int32), out_ci, out_v
+
+
+def gather_csr_blocks(rowptr, colidx, vals, ncol_blocks, dst=0, group=None):
+    """2-D counterpart of gather_csr_slices: every rank contributes the CSR of its block (rank = i * Cb + j);
+    `dst` receives them point to point and splices them.  Returns the whole CSR on `dst`, None elsewhere."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = rowptr.device
+    meta = torch.tensor([rowptr.numel() - 1, colidx.numel()], dtype=torch.int64, device=dev)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    metas = torch.stack(metas).cpu().tolist()
+    if rank != dst:
+        ops = [dist.P2POp(dist.isend, rowptr, dst, group=group)]
+        if metas[rank][1] > 0:
+            ops.append(dist.P2POp(dist.isend, colidx, dst, group=group))
+            ops.append(dist.P2POp(dist.isend, vals, dst, group=group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return None
+    blocks, ops = [], []
+    for r in range(world):
+        if r == dst:
+            blocks.append((rowptr, colidx, vals))
+            continue
+        nr, nz = metas[r]
+        b = (torch.empty(nr + 1, dtype=torch.int32, device=dev), torch.empty(nz, dtype=torch.int32, device=dev),
+             torch.empty(nz, dtype=vals.dtype, device=dev))
+        ops.append(dist.P2POp(dist.irecv, b[0], r, group=group))
+        if nz > 0:
+            ops.append(dist.P2POp(dist.irecv, b[1], r, group=group))
+            ops.append(dist.P2POp(dist.irecv, b[2], r, group=group))
+        blocks.append(b)
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return assemble_csr_blocks(blocks, ncol_blocks)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SURVEY 8(f)-4, second half: overlap the gather with the computation of later tile-row chunks.  A rank's row block is
+# cut into chunks (one plan each, so repeat passes stay warm); chunk c is exported on the device and handed to the
+# communication backend -- asynchronous point-to-point, on the backend's own streams -- while chunk c+1 runs steps
+# 1-3 on the library's stream.  The root receives into per-(rank, chunk) staging buffers and concatenates them at the
+# end; chunk sizes are exchanged once (A and B are immutable, so they repeat) and cached.
+# ------------------------------------------------------------------------------------------------------------------
+def concat_csr_slices(slices):
+    """row-wise concatenation of CSR slices [(rowptr relative, colidx, vals), ...] in list order"""
+    dev = slices[0][0].device
+    nrows = [s[0].numel() - 1 for s in slices]
+    nnzs = [s[1].numel() for s in slices]
+    out_rp = torch.zeros(sum(nrows) + 1, dtype=torch.int32, device=dev)
+    out_ci = torch.empty(sum(nnzs), dtype=torch.int32, device=dev)
+    out_v = torch.empty(sum(nnzs), dtype=slices[0][2].dtype, device=dev)
+    ro = no = 0
+    for (rp, ci, v), nr, nz in zip(slices, nrows, nnzs):
+        out_rp[ro + 1:ro + nr + 1] = rp[1:] + no
+        out_ci[no:no + nz] = ci
+        out_v[no:no + nz] = v
+        ro += nr
+        no += nz
+    return out_rp, out_ci, out_v
+
+
+class ChunkedRowBlock:
+    """One rank's row block as `nchunks` plans whose CSR exports are sent while the next chunk computes."""
+
+    def __init__(self, pkg, ctx, A, B, bounds, rank, nchunks, torch_dtype, dst=0, group=None):
+        # bounds: pem_split_tile_rows(ctx, A, B, world * nchunks) -- product-balanced over ALL chunks of all ranks
+        self.pkg, self.ctx, self.dst, self.group = pkg, ctx, dst, group
+        self.rank, self.world, self.nchunks = rank, dist.get_world_size(group), nchunks
+        self.plans = [pkg.CPlan(ctx, A, B, int(bounds[rank * nchunks + c]), int(bounds[rank * nchunks + c + 1])) for c in range(nchunks)]
+        self.vdt = torch_dtype
+        self.bufs = [None] * nchunks
+        self.metas = None          # [world][nchunks] (nrows, nnz), known after the first pass
+        self.stage = None
+
+    def _export(self, c):
+        p = self.plans[c]
+        info = p.info()
+        nrows, nz = info["row_end"] - info["row_begin"], info["nnz_c"]
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if self.bufs[c] is None or self.bufs[c][1].numel() != nz:
+            self.bufs[c] = (torch.empty(nrows + 1, dtype=torch.int32, device=dev), torch.empty(nz, dtype=torch.int32, device=dev),
+                            torch.empty(nz, dtype=self.vdt, device=dev))
+        rp, ci, v = self.bufs[c]
+        dummy = rp   # export needs non-null pointers only when nnz > 0
+        p.export_csr_device(rp.data_ptr(), ci.data_ptr() if nz else dummy.data_ptr(), v.data_ptr() if nz else dummy.data_ptr())
+        self.ctx.synchronize()      # the export ran on the library's stream; the backend reads the buffers on its own
+        return nrows, nz
+
+    def _ensure_stage(self):
+        if self.rank != self.dst or self.stage is not None:
+            return
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.stage = [[None if r == self.dst else
+                       (torch.empty(self.metas[r][c][0] + 1, dtype=torch.int32, device=dev),
+                        torch.empty(self.metas[r][c][1], dtype=torch.int32, device=dev),
+                        torch.empty(self.metas[r][c][1], dtype=self.vdt, device=dev)) for c in range(self.nchunks)]
+                      for r in range(self.world)]
+
+    def run_pass(self):
+        """all chunks: compute, export, send (overlapped).  Returns the whole C as CSR on `dst`, None elsewhere."""
+        first = self.metas is None      # the root cannot post receives before it knows the sizes
+        works, my_meta = [], []
+        if not first:
+            self._ensure_stage()
+        for c in range(self.nchunks):
+            self.plans[c].spgemm()
+            my_meta.append(self._export(c))
+            if not first:
+                works += self._post(c)          # chunk c travels while chunk c+1 computes
+        if first:
+            dev = torch.device("cuda", torch.cuda.current_device())
+            t = torch.tensor(my_meta, dtype=torch.int64, device=dev)
+            allm = [torch.zeros_like(t) for _ in range(self.world)]
+            dist.all_gather(allm, t, group=self.group)
+            self.metas = [m.cpu().tolist() for m in allm]
+            self._ensure_stage()
+            for c in range(self.nchunks):
+                works += self._post(c)
+        for w in works:
+            w.wait()
+        return self._assemble()
+
+    def _post(self, c):
+        ops = []
+        if self.rank != self.dst:
+            rp, ci, v = self.bufs[c]
+            ops.append(dist.P2POp(dist.isend, rp, self.dst, group=self.group))
+            if ci.numel():
+                ops.append(dist.P2POp(dist.isend, ci, self.dst, group=self.group))
+                ops.append(dist.P2POp(dist.isend, v, self.dst, group=self.group))
+        else:
+            for r in range(self.world):
+                if r == self.dst:
+                    continue
+                rp, ci, v = self.stage[r][c]
+                ops.append(dist.P2POp(dist.irecv, rp, r, group=self.group))
+                if ci.numel():
+                    ops.append(dist.P2POp(dist.irecv, ci, r, group=self.group))
+                    ops.append(dist.P2POp(dist.irecv, v, r, group=self.group))
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def _assemble(self):
+        if self.rank != self.dst:
+            return None
+        slices = []
+        for r in range(self.world):
+            for c in range(self.nchunks):
+                slices.append(self.bufs[c] if r == self.dst else self.stage[r][c])
+        return concat_csr_slices(slices)

@@ -31,3 +31,28 @@ def test_two_ranks_on_one_card_agree_with_one_rank():
     for k in ("flop", "C_nnz", "C_tiles", "tile_pairs", "nnz"):
         assert one["config"][k] == two["config"][k], k
     assert two["value"] > 0 and two["scaling"] == "strong"
+
+
+def test_grid_partition_on_one_card_gathers_the_same_matrix():
+    """4 ranks as a 2x2 (row block of A) x (column block of B) grid against 2 row-block ranks: same flop,
+    same C, and the assembled CSR on the root has the same fingerprint (equal arrays give equal sums, value sums included)."""
+    two = _run(2, ["--workload", "scircuit", "--scale", "0.25"])
+    grid = _run(4, ["--workload", "scircuit", "--scale", "0.25", "--grid", "2x2"])
+    assert grid["n_gpus"] == 4 and grid["config"]["parallelism"] == "grid2x2+gather"
+    for k in ("flop", "C_nnz", "nnz"):
+        assert two["config"][k] == grid["config"][k], k
+    g2, g4 = two["exchange"]["gathered"], grid["exchange"]["gathered"]
+    assert g2 == g4 and g2["nnz"] == two["config"]["C_nnz"] == g2["rowptr_last"]
+    aat = _run(3, ["--workload", "mc2depi", "--scale", "0.05", "--grid", "1x3"])          # A*A^T, B split only
+    ref = _run(1, ["--workload", "mc2depi", "--scale", "0.05"])
+    assert aat["config"]["flop"] == ref["config"]["flop"] and aat["config"]["C_nnz"] == ref["config"]["C_nnz"]
+    assert aat["exchange"]["gathered"]["nnz"] == ref["config"]["C_nnz"]
+
+
+def test_chunked_pipeline_gathers_the_same_matrix():
+    """row blocks cut into chunks whose CSR travels while the next chunk computes -- same C on the root."""
+    r = _run(2, ["--workload", "scircuit", "--scale", "0.25", "--chunks", "3"])
+    pipe, g = r["exchange"]["pipelined"], r["exchange"]["gathered"]
+    assert pipe["chunks"] == 3 and pipe["ms_per_step"] > 0
+    fp = pipe["fingerprint"]
+    assert (fp["nnz"], fp["colidx_sum"], fp["rowptr_sum"], fp["vals_sum"]) == (g["nnz"], g["colidx_sum"], g["rowptr_sum"], g["vals_sum"])

@@ -51,3 +51,84 @@ def test_row_block_gather_equals_single_rank(world, bounds):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _worker_2d(rank, world, port, ncb, case, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as g
+    from matgen import cases
+    g.load_package()
+    mg = importlib.import_module("pem_spgemm_amd.multigpu")
+    o = g.load_oracle()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows, cols, I, J, V, tr = cases()[case]
+    BI, BJ = (J, I) if tr else (I, J)                      # B = A^T for the A*A^T cases
+    brows, bcols = (cols, rows) if tr else (rows, cols)
+    nrb = world // ncb
+    rb = mg.balanced_tile_bounds(I, rows, nrb)
+    cb = mg.balanced_tile_bounds(BJ, bcols, ncb)
+    i, j = mg.grid_coords(rank, ncb)
+    ma, mb = mg.restrict(I, rb[i], rb[i + 1]), mg.restrict(BJ, cb[j], cb[j + 1])
+    A = o.Tiled(rows, cols, I[ma], J[ma], V[ma])           # only this rank's rows of A ...
+    B = o.Tiled(brows, bcols, BI[mb], BJ[mb], V[mb])       # ... and columns of B; indices stay global
+    rp, ci, v = o.Plan(A, B, rb[i], rb[i + 1]).export_csr()
+    out = mg.gather_csr_blocks(torch.from_numpy(rp), torch.from_numpy(ci), torch.from_numpy(v), ncb, dst=0)
+    if rank == 0:
+        fa = o.Csr(rows, cols, I, J, V)
+        fb = o.Csr(rows, cols, I, J, V, tr)
+        full = o.csr_spgemm(fa, fb).arrays()
+        ok = all(np.array_equal(a.numpy(), b) for a, b in zip(out, full))
+        q.put(bool(ok))
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ncb,case", [(4, 2, "powerlaw_600"), (3, 3, "rand_300"), (4, 2, "rect_70x40_AAt"), (2, 1, "rand_300")])
+def test_2d_block_gather_equals_single_rank(world, ncb, case):
+    """(row block of A) x (column block of B) grid; no rank ever holds all of A or of B."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + world * 7 + ncb + (os.getpid() % 150)
+    procs = [ctx.Process(target=_worker_2d, args=(r, world, port, ncb, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_concat_and_assemble_helpers_on_cpu():
+    """the splicing used by the chunked pipeline and by the 2-D grid, against scipy slicing"""
+    import scipy.sparse as sp
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.load_package()
+    mg = importlib.import_module("pem_spgemm_amd.multigpu")
+    M = sp.random(83, 117, 0.15, random_state=5, format="csr")
+    M.sort_indices()
+
+    def t(block, c0=0):
+        block = block.tocsr()
+        block.sort_indices()
+        return (torch.from_numpy(block.indptr.astype(np.int32)), torch.from_numpy((block.indices + c0).astype(np.int32)),
+                torch.from_numpy(block.data.copy()))
+    cuts = [0, 16, 16, 48, 83]                                            # an empty slice in the middle
+    rp, ci, v = mg.concat_csr_slices([t(M[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert np.array_equal(rp.numpy(), M.indptr) and np.array_equal(ci.numpy(), M.indices) and np.array_equal(v.numpy(), M.data)
+    rb, cb = [0, 2, 6], [0, 3, 3, 8]                                      # tile bounds; an empty column block
+    blocks = []
+    for i in range(2):
+        for j in range(3):
+            r0, r1, c0, c1 = 16 * rb[i], min(16 * rb[i + 1], 83), 16 * cb[j], min(16 * cb[j + 1], 117)
+            blocks.append(t(M[r0:r1].tocsc()[:, c0:c1], c0))
+    rp, ci, v = mg.assemble_csr_blocks(blocks, 3)
+    assert np.array_equal(rp.numpy(), M.indptr) and np.array_equal(ci.numpy(), M.indices) and np.array_equal(v.numpy(), M.data)
+    I = M.tocoo().row
+    b = mg.balanced_tile_bounds(I, 83, 4)
+    assert b[0] == 0 and b[-1] == 6 and all(x <= y for x, y in zip(b, b[1:]))
+    assert mg.restrict(I, b[1], b[2]).sum() == ((I >= 16 * b[1]) & (I < 16 * b[2])).sum()
