@@ -39,7 +39,7 @@ def kernel_alg_bytes(name, d):
         "s2_cmask_kernel": 8 * P + 32 * TA + 32 * TB + 36 * TC,
         "s2_crowcol_kernel": 36 * TC + 16 * TC + NZ,
         "s3_accumulate_kernel": 8 * P + 8 * TC + NZ + (vb * nA + 52 * TA) + (vb * nB + 84 * TB) + vb * NZ,
-        "s2_cmask_wide_kernel": 8 * P + 32 * TA + 32 * TB + 52 * TC,
+        "s2_cmask_wide_kernel": 8 * P + 32 * TA + 32 * TB + 36 * TC,
         "s2_crowcol_wide_kernel": 36 * TC + NZ,
         "s3_accumulate_wide_kernel": 8 * P + 8 * TC + NZ + (vb * nA + 68 * TA) + (vb * nB + 100 * TB) + vb * NZ,
         "s1_rowsort_kernel<512>": None, "s1_rowsort_kernel<2048>": None, "s1_rowsort_kernel<8192>": None,

@@ -186,7 +186,9 @@ struct pem_cplan {
     int64_t ntiles_c = 0, npairs = 0, nnz_c = 0;
     pem::DevBuf c_tile_rowptr, c_tile_rowidx, c_tile_colidx;
     pem::DevBuf pairs_offset, pairs_a, pairs_b;
-    pem::DevBuf c_mask, c_tile_nnz_ptr, c_rowptr, c_rowcolidx, c_vals;
+    pem::DevBuf c_mask, c_tile_nnz_ptr, c_rowcolidx, c_vals;
+    mutable pem::DevBuf c_rowptr;      // Ctiles_rowPtr: materialised on demand from c_mask (nothing on the default path reads it)
+    mutable bool c_rowptr_valid = false;
     // step-1 products kept for step 2 (expanded pair ids + the sorted permutation)
     pem::DevBuf prod_a, prod_b, aprod_off;
     pem::DevBuf lprod_off;             // like aprod_off, counting only products whose tiles can meet (live products)

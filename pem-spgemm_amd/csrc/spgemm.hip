@@ -854,8 +854,7 @@ __global__ void __launch_bounds__(256) s3_accumulate_kernel(
 __global__ void __launch_bounds__(256) s2_cmask_wide_kernel(const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a,
                                                             const int *__restrict__ pairs_b, long long ntc,
                                                             const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks,
-                                                            uint32_t *__restrict__ c_mask, int *__restrict__ c_tile_nnz,
-                                                            uint8_t *__restrict__ c_rowptr)
+                                                            uint32_t *__restrict__ c_mask, int *__restrict__ c_tile_nnz)
 {
     // B's 16 row masks of the lane's current pair, [dword q][lane]: a lane only ever reads what it
     // wrote itself (same wave, program order), so no barrier is needed
@@ -891,21 +890,37 @@ __global__ void __launch_bounds__(256) s2_cmask_wide_kernel(const int *__restric
     }
     // reference packing: word q = (row 2q) << 16 | row 2q+1  (spgemm.cu:533-543)
     unsigned out[8];
+    int run = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        out[q] = (cw[q] << 16) | (cw[q] >> 16);   // rows 2q, 2q+1 swap halves
+        run += __popc(cw[q]);
+    }
+    *reinterpret_cast<uint4 *>(c_mask + 8 * t) = make_uint4(out[0], out[1], out[2], out[3]);
+    *reinterpret_cast<uint4 *>(c_mask + 8 * t + 4) = make_uint4(out[4], out[5], out[6], out[7]);
+    c_tile_nnz[t] = run;
+}
+
+// Ctiles_rowPtr (spgemm.cu:579-580) from the stored masks, one C tile per lane.  Nothing on the default path reads
+// it (step 3 and the export work from the masks), so it is materialised on demand: 16 bytes per C tile that the
+// mask kernel no longer writes on every pass (0.3 GB on webbase-1M).
+__global__ void __launch_bounds__(256) s2_crowptr_kernel(const uint32_t *__restrict__ c_mask, long long ntc, uint8_t *__restrict__ c_rowptr)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntc) return;
+    const uint4 M0 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t);
+    const uint4 M1 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t + 4);
+    const unsigned w[8] = {M0.x, M0.y, M0.z, M0.w, M1.x, M1.y, M1.z, M1.w};   // word q = (row 2q) << 16 | row 2q+1
     unsigned rp[4] = {0, 0, 0, 0};
     int run = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const unsigned lo = cw[q] & 0xFFFFu, hi = cw[q] >> 16;   // rows 2q, 2q+1
-        out[q] = (lo << 16) | hi;
         rp[q >> 1] |= (unsigned)run << (16 * (q & 1));
-        run += __popc(lo);
+        run += __popc(w[q] >> 16);
         rp[q >> 1] |= (unsigned)run << (16 * (q & 1) + 8);
-        run += __popc(hi);
+        run += __popc(w[q] & 0xFFFFu);
     }
-    *reinterpret_cast<uint4 *>(c_mask + 8 * t) = make_uint4(out[0], out[1], out[2], out[3]);
-    *reinterpret_cast<uint4 *>(c_mask + 8 * t + 4) = make_uint4(out[4], out[5], out[6], out[7]);
     *reinterpret_cast<uint4 *>(c_rowptr + 16 * t) = make_uint4(rp[0], rp[1], rp[2], rp[3]);
-    c_tile_nnz[t] = run;
 }
 
 // a12 (spgemm.cu:582-587): packed (r<<4|c) bytes, one C tile per lane
@@ -1586,7 +1601,7 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
     PEM_TRY(p->pairs_b.reserve(sizeof(int) * (n + 4)));
     PEM_TRY(p->c_mask.reserve(sizeof(uint32_t) * 8 * (ntc + 1)));
     PEM_TRY(p->c_tile_nnz_ptr.reserve(sizeof(int) * (ntc + 4)));
-    PEM_TRY(p->c_rowptr.reserve(16 * (ntc + 1)));
+    p->c_rowptr_valid = false;
     if (n > 0 && !p->pairs_ready)
         PEM_LAUNCH(ctx, s2_pairs_kernel, grid_for(n, 256), 256, p->sorted_perm, p->prod_a.as<int>(), p->prod_b.as<int>(), n, p->pairs_a.as<int>(),
                    p->pairs_b.as<int>());
@@ -1595,8 +1610,7 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
     if (ntc > 0) {
         if (wide)
             PEM_LAUNCH(ctx, s2_cmask_wide_kernel, grid_for(ntc, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
-                       (long long)ntc, A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>(),
-                       p->c_rowptr.as<uint8_t>());
+                       (long long)ntc, A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>());
         else
             PEM_LAUNCH(ctx, s2_cmask_kernel, grid_for(ntc * 16, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
                        (long long)ntc, A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>());
@@ -1620,9 +1634,12 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
         if (wide)
             PEM_LAUNCH(ctx, s2_crowcol_wide_kernel, grid_for(ntc, 256), 256, p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
                        p->c_rowcolidx.as<uint8_t>());
-        else
+        else {   // the 16-lanes-per-tile baseline writes Ctiles_rowPtr as it goes, like the reference (spgemm.cu:579-580)
+            PEM_TRY(p->c_rowptr.reserve(16 * (ntc + 1)));
             PEM_LAUNCH(ctx, s2_crowcol_kernel, grid_for(ntc * 16, 256), 256, p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
                        p->c_rowptr.as<uint8_t>(), p->c_rowcolidx.as<uint8_t>());
+            p->c_rowptr_valid = true;
+        }
     }
     PEM_HIP(hipEventRecord(ctx->ev[3], st));
     p->state = 2;
@@ -1731,6 +1748,18 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
     return PEM_OK;
 }
 
+// Ctiles_rowPtr on demand (see s2_crowptr_kernel)
+static pem_status ensure_c_rowptr(pem_ctx *ctx, const pem_cplan *p)
+{
+    if (p->c_rowptr_valid || p->state < 2) return PEM_OK;
+    const size_t ntc = (size_t)p->ntiles_c;
+    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_TRY(p->c_rowptr.reserve(16 * (ntc + 1)));
+    if (ntc > 0) PEM_LAUNCH(ctx, s2_crowptr_kernel, grid_for(ntc, 256), 256, p->c_mask.as<uint32_t>(), (long long)ntc, p->c_rowptr.as<uint8_t>());
+    p->c_rowptr_valid = true;
+    return PEM_OK;
+}
+
 extern "C" pem_status pem_cplan_get_array(pem_ctx *ctx, const pem_cplan *p, pem_cplan_array which, void *host_dst, int64_t bytes)
 {
     if (!ctx || !p || (!host_dst && bytes > 0)) return PEM_E_INVALID;
@@ -1747,7 +1776,12 @@ extern "C" pem_status pem_cplan_get_array(pem_ctx *ctx, const pem_cplan *p, pem_
     case PEM_C_PAIRS_B: src = p->pairs_b.p; want = 4 * P; need = 2; break;
     case PEM_C_MASK: src = p->c_mask.p; want = 32 * TC; need = 2; break;
     case PEM_C_TILE_NNZ_PTR: src = p->c_tile_nnz_ptr.p; want = 4 * (TC + 1); need = 2; break;
-    case PEM_C_ROWPTR: src = p->c_rowptr.p; want = 16 * TC; need = 2; break;
+    case PEM_C_ROWPTR:
+        PEM_TRY(ensure_c_rowptr(ctx, p));
+        src = p->c_rowptr.p;
+        want = 16 * TC;
+        need = 2;
+        break;
     case PEM_C_ROWCOLIDX: src = p->c_rowcolidx.p; want = NZ; need = 2; break;
     case PEM_C_VALS: src = p->c_vals.p; want = (size_t)p->A->value_bytes * NZ; need = 3; break;   // native type
     default: set_error("unknown pem_cplan_array %d", (int)which); return PEM_E_INVALID;
@@ -1795,6 +1829,7 @@ static pem_status export_csr_device_impl(pem_ctx *ctx, const pem_cplan *p, int32
     PEM_HIP(hipMemsetAsync(d_rowptr, 0, sizeof(int) * ((size_t)nrows + 1), st));
     const char *narrow = getenv("PEM_EXPORT");
     if (mt > 0 && nrows > 0 && narrow && !strcmp(narrow, "rows")) {   // 16 lanes per tile row, serial over its tiles (A/B baseline)
+        PEM_TRY(ensure_c_rowptr(ctx, p));
         PEM_LAUNCH(ctx, ex_rowcount_kernel, grid_for((size_t)mt * 16, 256), 256, p->c_tile_rowptr.as<int>(), p->c_mask.as<uint16_t>(), mt, nrows,
                    d_rowptr);
         PEM_TRY(exclusive_scan_i32(ctx, d_rowptr, d_rowptr, (size_t)nrows, nullptr));
