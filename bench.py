@@ -43,7 +43,7 @@ def kernel_alg_bytes(name, d):
         "s2_crowcol_wide_kernel": 36 * TC + NZ,
         "s3_accumulate_wide_kernel": 8 * P + 8 * TC + NZ + (vb * nA + 68 * TA) + (vb * nB + 100 * TB) + vb * NZ,
         "s1_rowsort_kernel<512>": None, "s1_rowsort_kernel<2048>": None, "s1_rowsort_kernel<8192>": None,
-        "s1_compact_kernel": 20 * TC,
+        "s1_compact_kernel": 16 * TC,
     }
     for suffix in ("<double>", "<float>"):          # value-typed kernels carry their template argument in the name
         if name.endswith(suffix):

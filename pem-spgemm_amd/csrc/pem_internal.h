@@ -184,7 +184,9 @@ struct pem_cplan {
     int a_lo = 0, a_hi = 0;            // A tile id range of the slice
     int state = 0;                     // 0 created, 1 step1 done, 2 step2 done, 3 step3 done
     int64_t ntiles_c = 0, npairs = 0, nnz_c = 0;
-    pem::DevBuf c_tile_rowptr, c_tile_rowidx, c_tile_colidx;
+    pem::DevBuf c_tile_rowptr, c_tile_colidx;
+    mutable pem::DevBuf c_tile_rowidx; // _C_tileRowIdx: on demand from c_tile_rowptr on the row-local path (no reader there)
+    mutable bool c_rowidx_valid = false;
     pem::DevBuf pairs_offset, pairs_a, pairs_b;
     pem::DevBuf c_mask, c_tile_nnz_ptr, c_rowcolidx, c_vals;
     mutable pem::DevBuf c_rowptr;      // Ctiles_rowPtr: materialised on demand from c_mask (nothing on the default path reads it)

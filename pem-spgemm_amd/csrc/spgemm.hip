@@ -701,7 +701,7 @@ __global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint3
 __global__ void __launch_bounds__(256) s1_compact_kernel(const int *__restrict__ c_rowptr, int mt, long long ntc, int tr_lo,
                                                          const int *__restrict__ a_tile_rowptr, int a_lo, const int *__restrict__ aprod_off,
                                                          const int *__restrict__ scratch_col, const int *__restrict__ scratch_off, int npairs,
-                                                         int *__restrict__ c_rowidx, int *__restrict__ c_colidx, int *__restrict__ pairs_offset)
+                                                         int *__restrict__ c_colidx, int *__restrict__ pairs_offset)
 {
     const int lane = threadIdx.x & 63;
     const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -710,12 +710,21 @@ __global__ void __launch_bounds__(256) s1_compact_kernel(const int *__restrict__
         if (cnt == 0) continue;
         const int p0 = aprod_off[a_tile_rowptr[tr_lo + i] - a_lo];
         for (int r = lane; r < cnt; r += 64) {
-            c_rowidx[t0 + r] = i + tr_lo;
             c_colidx[t0 + r] = scratch_col[p0 + r];
             pairs_offset[t0 + r] = p0 + scratch_off[p0 + r];
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) pairs_offset[ntc] = npairs;
+}
+
+// _C_tileRowIdx (spgemm.cu:378) from _C_rowPtr, one wave per tile row.  Like Ctiles_rowPtr it has no reader on the
+// default path (every consumer walks tile rows through _C_rowPtr) and is materialised on demand.
+__global__ void __launch_bounds__(256) s1_crowidx_kernel(const int *__restrict__ c_rowptr, int mt, int tr_lo, int *__restrict__ c_rowidx)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave; i < mt; i += nwaves)
+        for (int t = c_rowptr[i] + lane; t < c_rowptr[i + 1]; t += 64) c_rowidx[t] = i + tr_lo;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1373,6 +1382,7 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
         PEM_LAUNCH(ctx, s1_emit_ctiles_kernel, grid_for(n, 256), 256, keys, head.as<int>(), n, p->tr_lo, bits_tc, p->c_tile_rowidx.as<int>(),
                    p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>());
+        p->c_rowidx_valid = true;
         PEM_LAUNCH(ctx, s1_c_rowptr_kernel, grid_for(ntc, 256), 256, p->c_tile_rowidx.as<int>(), (long long)TC, p->tr_lo, mt,
                    p->c_tile_rowptr.as<int>());
     } else {
@@ -1461,6 +1471,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     const int qcap = k32 ? (1 << 15) : (1 << 24);
     p->state = 0;
     p->pairs_ready = false;
+    p->c_rowidx_valid = false;
     p->ntiles_c = p->npairs = p->nnz_c = 0;
     PEM_HIP(hipEventRecord(ctx->ev[0], st));
     PEM_TRY(p->c_tile_rowptr.reserve(sizeof(int) * ((size_t)mt + 4)));
@@ -1560,12 +1571,11 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
             p->w_TC = TC;
         }
         const size_t ntc = (size_t)TC;
-        PEM_TRY(p->c_tile_rowidx.reserve(sizeof(int) * (ntc + 4)));
         PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
         PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
         PEM_LAUNCH(ctx, s1_compact_kernel, grid_for((size_t)mt * 64, 256), 256, p->c_tile_rowptr.as<int>(), mt, (long long)TC, p->tr_lo,
                    A->tile_rowptr.as<int>(), p->a_lo, p->lprod_off.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), (int)P,
-                   p->c_tile_rowidx.as<int>(), p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>());
+                   p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>());
         p->pairs_ready = true;
     }
     p->ntiles_c = TC;
@@ -1748,6 +1758,19 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
     return PEM_OK;
 }
 
+// _C_tileRowIdx on demand (see s1_crowidx_kernel)
+static pem_status ensure_c_rowidx(pem_ctx *ctx, const pem_cplan *p)
+{
+    if (p->c_rowidx_valid || p->state < 1) return PEM_OK;
+    const int mt = p->tr_hi - p->tr_lo;
+    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_TRY(p->c_tile_rowidx.reserve(sizeof(int) * ((size_t)p->ntiles_c + 4)));
+    if (mt > 0 && p->ntiles_c > 0)
+        PEM_LAUNCH(ctx, s1_crowidx_kernel, grid_for((size_t)mt * 64, 256), 256, p->c_tile_rowptr.as<int>(), mt, p->tr_lo, p->c_tile_rowidx.as<int>());
+    p->c_rowidx_valid = true;
+    return PEM_OK;
+}
+
 // Ctiles_rowPtr on demand (see s2_crowptr_kernel)
 static pem_status ensure_c_rowptr(pem_ctx *ctx, const pem_cplan *p)
 {
@@ -1769,7 +1792,11 @@ extern "C" pem_status pem_cplan_get_array(pem_ctx *ctx, const pem_cplan *p, pem_
     int need = 1;
     switch (which) {
     case PEM_C_TILE_ROWPTR: src = p->c_tile_rowptr.p; want = 4 * (mt + 1); break;
-    case PEM_C_TILE_ROWIDX: src = p->c_tile_rowidx.p; want = 4 * TC; break;
+    case PEM_C_TILE_ROWIDX:
+        PEM_TRY(ensure_c_rowidx(ctx, p));
+        src = p->c_tile_rowidx.p;
+        want = 4 * TC;
+        break;
     case PEM_C_TILE_COLIDX: src = p->c_tile_colidx.p; want = 4 * TC; break;
     case PEM_C_PAIRS_OFFSET: src = p->pairs_offset.p; want = 4 * (TC + 1); break;
     case PEM_C_PAIRS_A: src = p->pairs_a.p; want = 4 * P; need = 2; break;
