@@ -175,6 +175,13 @@ typedef enum {
 } pem_cplan_array;
 pem_status pem_cplan_get_array(pem_ctx *ctx, const pem_cplan *plan, pem_cplan_array which, void *host_dst, int64_t bytes);
 
+/* Graph replay of repeat passes (off by default; PEM_GRAPH=1 in the environment turns it on at context creation).
+ * The reference's timed loop re-launches every kernel of every pass (spgemm.cu:1133-1357).  With replay on, the second
+ * and later pem_spgemm calls on an unchanged plan run as ONE hipGraph captured from the first repeat pass (same
+ * kernels, grids and buffers: results are identical).  A replayed pass has no per-step events, so pem_timings reports
+ * step1/2/3_ms = 0 for it and only spgemm_wall_ms; take the step split from a pass made with replay off. */
+pem_status pem_set_graph_replay(pem_ctx *ctx, int on);
+
 /* ---- a14: tiled C -> CSR / sorted COO (spgemm.cu:663-695, 1493-1543) ------------------- */
 /* rowptr has (row_end-row_begin)+1 entries and is relative to the slice (rowptr[0] = 0);
  * column indices ascend inside a row.  COO rows are absolute, sorted by (row, col). */

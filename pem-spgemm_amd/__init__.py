@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "pem_c_export_coo", "pem_split_tile_rows", "pem_get_timings", "pem_set_kernel_profiling", "pem_reset_kernel_stats",
     "pem_kernel_stats_count", "pem_kernel_stats_get", "pem_tiled_save", "pem_tiled_load",
     "pem_tiled_from_coo_f32", "pem_tiled_from_coo_device_f32", "pem_tiled_from_csr_f32", "pem_c_export_csr_f32",
-    "pem_c_export_csr_device_f32", "pem_c_export_coo_f32",
+    "pem_c_export_csr_device_f32", "pem_c_export_coo_f32", "pem_set_graph_replay",
 ]
 
 
@@ -120,6 +120,10 @@ class Context:
         t = Timings()
         _check(lib().pem_get_timings(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in Timings._fields_}
+
+    def set_graph_replay(self, on):
+        """repeat passes of CPlan.spgemm() replayed as one hipGraph (no per-step timings for those passes)"""
+        _check(lib().pem_set_graph_replay(self._h, int(bool(on))))
 
     def set_kernel_profiling(self, on):
         _check(lib().pem_set_kernel_profiling(self._h, int(bool(on))))

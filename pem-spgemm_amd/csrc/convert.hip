@@ -286,6 +286,8 @@ extern "C" pem_status pem_ctx_create_on_stream(int device, void *stream, pem_ctx
     PEM_HIP(hipMemsetAsync(ctx->d_flags, 0, sizeof(int) * NUM_FLAGS, ctx->stream));
     for (auto &ev : ctx->ev) PEM_HIP(hipEventCreate(&ev));
     for (auto &a : ctx->aux) PEM_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+    const char *graph_env = getenv("PEM_GRAPH");   // default for pem_set_graph_replay (tools, CLI)
+    ctx->graph_replay = graph_env && !strcmp(graph_env, "1");
     PEM_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for (auto &e : ctx->ev_join) PEM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     PEM_HIP(hipStreamSynchronize(ctx->stream));

@@ -32,6 +32,13 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 // Grow-only device buffer.  Contents are NOT preserved across a growth.
+// bumped whenever any device buffer is (re)allocated or freed: a captured pass (hipGraph) bakes buffer addresses in
+inline unsigned long long &alloc_generation()
+{
+    static unsigned long long gen = 0;
+    return gen;
+}
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -41,7 +48,10 @@ struct DevBuf {
     ~DevBuf() { release(); }
     void release()
     {
-        if (p) (void)hipFree(p);
+        if (p) {
+            (void)hipFree(p);
+            ++alloc_generation();
+        }
         p = nullptr;
         cap = 0;
     }
@@ -50,6 +60,7 @@ struct DevBuf {
         if (bytes <= cap) return PEM_OK;
         release();
         size_t want = (bytes + 255) & ~size_t(255);
+        ++alloc_generation();
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
             p = nullptr;
@@ -90,6 +101,8 @@ struct pem_ctx {
     // shared temporaries (grow-only, reused by every call on this context)
     pem::DevBuf scan_bsum;             // block sums of the device scan
     pem::DevBuf sort_hist;             // radix-sort histograms
+    bool graph_replay = false;         // pem_set_graph_replay: repeat passes of pem_spgemm are replayed as one hipGraph
+    bool capturing = false;            // a warm pass is being captured into a hipGraph: no timing events, no syncs
     bool chain_events = false;         // pem_spgemm: steps run back to back, boundary events are shared
     pem::DevBuf tmp[12];               // step/convert temporaries, see call sites
     // timing
@@ -202,6 +215,8 @@ struct pem_cplan {
     bool pairs_ready = false;          // step 1 already wrote pairs_a / pairs_b
     // sizes of the last complete pass on this plan.  A and B are immutable, so a repeat pass has the same
     // sizes: it skips the three host read-backs and a device-side check compares them at the end instead.
+    hipGraphExec_t graph_exec = nullptr;   // PEM_GRAPH=1: the captured warm pass
+    unsigned long long graph_gen = 0;      // alloc_generation() at capture time
     bool warm = false, warm_pass = false;
     int64_t w_P = 0, w_Pall = 0, w_TC = 0, w_nnz = 0;
     int w_counts[4] = {0, 0, 0, 0};

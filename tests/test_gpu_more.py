@@ -167,3 +167,46 @@ def test_cli_distinct_b_and_mtx_output(pkg, oracle, standins, tmp_path):
     # shape mismatch is refused
     out = subprocess.run([hostio.CLI_PATH, fa, "0", "--B", fa], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 1 and "inner dimensions differ" in out.stdout
+
+
+def test_graph_replay_is_bit_identical_and_survives_reallocation(pkg, oracle, ctx):
+    """pem_set_graph_replay: repeat passes run as one captured hipGraph.  Same arrays as plain launches; the graph is
+    re-captured when buffers were reallocated in between (an export, another plan growing the context's scratch)."""
+    from matgen import cases
+    from prune_ref import expected
+    names = ["powerlaw_600", "blockrows_1600", "rect_70x40_AAt", "hub_row_4000"]
+    plans, wants = [], []
+    for name in names:
+        rows, cols, I, J, V, tr = cases()[name]
+        A = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V)
+        B = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V, True) if tr else A
+        oA = oracle.Tiled(rows, cols, I, J, V)
+        oB = oracle.Tiled(rows, cols, I, J, V, True) if tr else oA
+        p = pkg.CPlan(ctx, A, B)
+        p.spgemm()
+        plans.append((p, A, B))
+        wants.append(expected(oracle.Plan(oA, oB), oA, oB)[0])
+    ctx.set_graph_replay(True)
+    try:
+        for rnd in range(3):                                  # interleaved plans: each keeps its own graph
+            for (p, _, _), want in zip(plans, wants):
+                p.spgemm()
+                t = ctx.timings()
+                assert t["step1_ms"] == 0.0 and t["spgemm_wall_ms"] > 0.0     # replayed: no step split
+                for arr in ("pairs_a", "pairs_b", "c_mask", "c_tile_nnz_ptr", "c_rowcolidx", "c_vals", "c_tile_rowidx", "c_rowptr"):
+                    assert np.array_equal(p.array(arr), want[arr]), (rnd, arr)
+                if rnd == 1:
+                    p.export_csr()                            # grows export scratch -> next replay must re-capture
+        # a much larger plan on the same context grows the shared scan / sort scratch under the old graphs
+        rows, cols, I, J, V, _ = cases()["blockrows_10000"]
+        big = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V)
+        pb = pkg.CPlan(ctx, big, big)
+        pb.spgemm()
+        pb.spgemm()
+        for (p, _, _), want in zip(plans, wants):
+            p.spgemm()
+            assert np.array_equal(p.array("c_vals"), want["c_vals"])
+    finally:
+        ctx.set_graph_replay(False)
+    plans[0][0].spgemm()
+    assert ctx.timings()["step1_ms"] > 0.0                    # replay off: step split is back

@@ -32,4 +32,4 @@ for p in ([part] if part >= 0 else range(nparts)):
     tm = ctx.timings()
     info = plan.info()
     print(f"{name} part {p}/{nparts}: tile rows [{bounds[p]}, {bounds[p + 1]})  {ms:.3f} ms/pass  step1 {tm['step1_ms']:.3f} step2 {tm['step2_ms']:.3f} "
-          f"step3 {tm['step3_ms']:.3f}  pairs {info['npairs']} C nnz {info['nnz_c']}")
+          f"step3 {tm['step3_ms']:.3f}  pairs {info['npairs']} (all {info['npairs_all']}) C tiles {info['ntiles_c']} C nnz {info['nnz_c']}")
