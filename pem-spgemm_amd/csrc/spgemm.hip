@@ -1421,13 +1421,15 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
     (void)hipEventRecord(ctx->ev_fork, main_stream);
     bool forked[3] = {false, false, false};
     int next_aux = -1;                     // -1: the main stream is still free
+    const bool serial = getenv("PEM_S1_SERIAL") != nullptr;   // diagnostic: every bin alone, one after the other
     auto bin_begin = [&]() {
-        if (next_aux < 0) return;
+        if (next_aux < 0 || serial) return;
         (void)hipStreamWaitEvent(ctx->aux[next_aux], ctx->ev_fork, 0);
         ctx->stream = ctx->aux[next_aux];
         forked[next_aux] = true;
     };
     auto bin_end = [&]() {
+        if (serial) return;
         if (next_aux >= 0) (void)hipEventRecord(ctx->ev_join[next_aux], ctx->aux[next_aux]);
         ctx->stream = main_stream;
         ++next_aux;
