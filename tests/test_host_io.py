@@ -90,3 +90,54 @@ def test_mtx_csr_writer_roundtrip(hostio, oracle, tmp_path):
     assert np.array_equal(M.data, v)                      # 17 significant digits: exact doubles
     back = hostio.mm_read(p)
     assert back["nnz"] == 120 and np.array_equal(back["V"], v)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_mm_reader_sweep_against_scipy(hostio, oracle, tmp_path, seed):
+    """seeded sweep over the header variants and text quirks a Matrix-Market file may legally carry -- field real /
+    integer / pattern, symmetry general / symmetric / skew-symmetric, comment and blank lines, tabs and trailing blanks,
+    exponents, upper-case keywords -- with scipy.io.mmread (scipy 1.15's reader IS fast_matrix_market, the library the
+    reference parses with: spgemm.cu:60-81) as the judge of what the file means"""
+    import scipy.io
+    rng = np.random.default_rng(7000 + seed)
+    field = ["real", "integer", "pattern"][seed % 3]
+    symm = ["general", "symmetric", "skew-symmetric"][(seed // 3) % 3]
+    if field == "pattern" and symm == "skew-symmetric":
+        symm = "symmetric"                                   # the format has no skew pattern matrices
+    n = int(rng.integers(3, 60))
+    m = n if symm != "general" else int(rng.integers(3, 60))
+    keys = rng.choice(n * m, int(rng.integers(1, max(2, n * m // 3))), replace=False)
+    I, J = keys // m, keys % m
+    if symm != "general":
+        keep = I > J if symm == "skew-symmetric" else I >= J        # stored triangle only
+        I, J = I[keep], J[keep]
+        if len(I) == 0:
+            I, J = np.array([n - 1]), np.array([0])
+    vals = rng.uniform(-50, 50, len(I))
+    lines = ["%%MatrixMarket" + f" matrix coordinate {field.upper() if seed % 4 == 1 else field} {symm}",
+             "% a comment", "%", f"{n} {m} {len(I)}" + ("  " if seed % 2 else "")]
+    for r, (i, j, v) in enumerate(zip(I, J, vals)):
+        sep = "\t" if (r + seed) % 5 == 0 else " " * (1 + (r % 3))
+        if field == "pattern":
+            lines.append(f"{i + 1}{sep}{j + 1}")
+        elif field == "integer":
+            lines.append(f"{i + 1}{sep}{j + 1}{sep}{int(v) if int(v) else 3}")
+        else:
+            lines.append(f"{i + 1}{sep}{j + 1}{sep}" + (f"{v:.17e}" if r % 2 else repr(float(v))) + (" " if r % 7 == 0 else ""))
+        if r == 2:
+            lines.append("")                                  # a blank line inside the data
+    p = tmp_path / f"s{seed}.mtx"
+    # (no final newline only for general files: scipy 1.15's reader crashes on a skew-symmetric file without one)
+    p.write_text("\n".join(lines) + ("\n" if seed % 3 or symm != "general" else ""))
+    want = scipy.io.mmread(str(p)).tocsr()
+    want.sort_indices()
+    for reader in (hostio.mm_read, oracle.mm_read):
+        got = reader(str(p))
+        assert (got["rows"], got["cols"]) == want.shape
+        import scipy.sparse as sp
+        G = sp.coo_matrix((got["V"], (got["I"], got["J"])), shape=want.shape)
+        assert G.nnz == len(got["V"])
+        G = G.tocsr()                                          # would sum duplicates: the nnz check below catches any
+        G.sort_indices()
+        assert G.nnz == want.nnz and np.array_equal(G.indptr, want.indptr) and np.array_equal(G.indices, want.indices)
+        assert np.array_equal(G.data, want.data), (field, symm)
