@@ -125,7 +125,16 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const int *__
     size_t base = (size_t)blockIdx.x * SCAN_BLOCK_ITEMS;
     size_t end = base + SCAN_BLOCK_ITEMS < n ? base + SCAN_BLOCK_ITEMS : n;
     long long s = 0;
-    for (size_t i = base + threadIdx.x; i < end; i += SCAN_THREADS) s += in[i];
+    if (end - base == (size_t)SCAN_BLOCK_ITEMS && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {   // full block: 16-byte loads
+        const int4 *in4 = reinterpret_cast<const int4 *>(in + base);
+#pragma unroll
+        for (int k = 0; k < SCAN_BLOCK_ITEMS / 4 / SCAN_THREADS; ++k) {
+            const int4 q = in4[k * SCAN_THREADS + threadIdx.x];
+            s += (long long)q.x + q.y + q.z + q.w;
+        }
+    } else {
+        for (size_t i = base + threadIdx.x; i < end; i += SCAN_THREADS) s += in[i];
+    }
     s = wave_reduce_sum(s);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -221,20 +230,24 @@ constexpr size_t SCAN_SMALL = 65536;
 __global__ void __launch_bounds__(1024) scan_small_kernel(const int *in, int *out, size_t n, long long *__restrict__ total64,
                                                           int *__restrict__ flags)
 {
+    // eight items per thread and trip (two 16-byte loads): half the trips, and barriers, of a four-item loop
     __shared__ int wsum[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long long carry = 0;
-    for (size_t base = 0; base < n; base += 4096) {
-        const size_t i0 = base + (size_t)threadIdx.x * 4;
-        int v[4];
-        if (i0 + 4 <= n) {
-            const int4 q = *reinterpret_cast<const int4 *>(in + i0);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    for (size_t base = 0; base < n; base += 8192) {
+        const size_t i0 = base + (size_t)threadIdx.x * 8;
+        int v[8];
+        if (i0 + 8 <= n) {
+            const int4 q0 = *reinterpret_cast<const int4 *>(in + i0), q1 = *reinterpret_cast<const int4 *>(in + i0 + 4);
+            v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
+            v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? in[i0 + k] : 0;
+            for (int k = 0; k < 8; ++k) v[k] = (i0 + k < n) ? in[i0 + k] : 0;
         }
-        const int tsum = v[0] + v[1] + v[2] + v[3];
+        int tsum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tsum += v[k];
         const int inc = wave_inclusive_scan(tsum);
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
@@ -245,13 +258,17 @@ __global__ void __launch_bounds__(1024) scan_small_kernel(const int *in, int *ou
             if (w < wave) woff += c;
             btotal += c;
         }
-        const int o0 = (int)carry + woff + inc - tsum, o1 = o0 + v[0], o2 = o1 + v[1], o3 = o2 + v[2];
-        if (i0 + 4 <= n) {
-            *reinterpret_cast<int4 *>(out + i0) = make_int4(o0, o1, o2, o3);
+        int o[8];
+        o[0] = (int)carry + woff + inc - tsum;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) o[k] = o[k - 1] + v[k - 1];
+        if (i0 + 8 <= n) {
+            *reinterpret_cast<int4 *>(out + i0) = make_int4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<int4 *>(out + i0 + 4) = make_int4(o[4], o[5], o[6], o[7]);
         } else {
-            if (i0 < n) out[i0] = o0;
-            if (i0 + 1 < n) out[i0 + 1] = o1;
-            if (i0 + 2 < n) out[i0 + 2] = o2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (i0 + k < n) out[i0 + k] = o[k];
         }
         carry += btotal;
         __syncthreads();
@@ -301,7 +318,16 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan2_reduce_kernel(ScanPair sp,
     size_t base = (size_t)blockIdx.x * SCAN_BLOCK_ITEMS;
     size_t end = base + SCAN_BLOCK_ITEMS < n ? base + SCAN_BLOCK_ITEMS : n;
     long long s = 0;
-    for (size_t i = base + threadIdx.x; i < end; i += SCAN_THREADS) s += in[i];
+    if (end - base == (size_t)SCAN_BLOCK_ITEMS && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {   // full block: 16-byte loads
+        const int4 *in4 = reinterpret_cast<const int4 *>(in + base);
+#pragma unroll
+        for (int k = 0; k < SCAN_BLOCK_ITEMS / 4 / SCAN_THREADS; ++k) {
+            const int4 q = in4[k * SCAN_THREADS + threadIdx.x];
+            s += (long long)q.x + q.y + q.z + q.w;
+        }
+    } else {
+        for (size_t i = base + threadIdx.x; i < end; i += SCAN_THREADS) s += in[i];
+    }
     s = wave_reduce_sum(s);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
     __syncthreads();
