@@ -217,6 +217,7 @@ struct pem_cplan {
     // sizes: it skips the three host read-backs and a device-side check compares them at the end instead.
     hipGraphExec_t graph_exec = nullptr;   // PEM_GRAPH=1: the captured warm pass
     unsigned long long graph_gen = 0;      // alloc_generation() at capture time
+    bool graph_failed = false;             // capture or instantiation failed once: plain launches from then on
     bool warm = false, warm_pass = false;
     int64_t w_P = 0, w_Pall = 0, w_TC = 0, w_nnz = 0;
     int w_counts[4] = {0, 0, 0, 0};

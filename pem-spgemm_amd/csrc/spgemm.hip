@@ -1768,60 +1768,63 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
     const bool use_graph = ctx->graph_replay && plan->warm && !ctx->profiling && !(mode_env && !strcmp(mode_env, "esc")) &&
                            !(nowarm_env && !strcmp(nowarm_env, "1"));
     bool graphed = false;
-    if (use_graph) {
+    if (use_graph && !plan->graph_failed) {
         if (plan->graph_exec && plan->graph_gen != pem::alloc_generation()) {
             (void)hipGraphExecDestroy(plan->graph_exec);
             plan->graph_exec = nullptr;
         }
-        if (!plan->graph_exec) {
+        if (!plan->graph_exec) {   // capture; any failure falls back to plain launches for the rest of the plan's life
             hipGraph_t graph = nullptr;
-            ctx->capturing = true;
             pem_status cs = PEM_OK;
-            if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) cs = PEM_E_HIP;
-            if (cs == PEM_OK) cs = step1_impl(ctx, plan, true);
-            if (cs == PEM_OK) cs = step2_impl(ctx, plan);
-            if (cs == PEM_OK) cs = step3_impl(ctx, plan);
-            if (cs == PEM_OK) launch_verify();
-            hipError_t ee = hipStreamEndCapture(ctx->stream, &graph);
-            ctx->capturing = false;
-            if (cs != PEM_OK || ee != hipSuccess || !graph) {
+            if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                ctx->capturing = true;
+                cs = step1_impl(ctx, plan, true);
+                if (cs == PEM_OK) cs = step2_impl(ctx, plan);
+                if (cs == PEM_OK) cs = step3_impl(ctx, plan);
+                if (cs == PEM_OK) launch_verify();
+                const hipError_t ee = hipStreamEndCapture(ctx->stream, &graph);
+                ctx->capturing = false;
+                if (cs == PEM_OK && ee == hipSuccess && graph &&
+                    hipGraphInstantiate(&plan->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess)
+                    plan->graph_gen = pem::alloc_generation();
+                else
+                    plan->graph_exec = nullptr;
                 if (graph) (void)hipGraphDestroy(graph);
-                set_error("pem_spgemm: capturing the pass into a graph failed (%s)", hipGetErrorString(ee));
-                return cs != PEM_OK ? cs : PEM_E_HIP;
             }
-            hipError_t ie = hipGraphInstantiate(&plan->graph_exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (ie != hipSuccess) {
+            if (!plan->graph_exec) {
+                (void)hipGetLastError();
+                plan->graph_failed = true;
+            }
+        }
+        if (plan->graph_exec) {
+            PEM_HIP(hipGraphLaunch(plan->graph_exec, ctx->stream));
+            int hf[NUM_FLAGS];
+            PEM_TRY(read_flags(ctx, hf));
+            if (hf[FLAG_CAPACITY]) {   // sizes differ from the captured ones (cannot happen while A and B are immutable)
+                (void)hipGraphExecDestroy(plan->graph_exec);
                 plan->graph_exec = nullptr;
-                set_error("pem_spgemm: hipGraphInstantiate failed: %s", hipGetErrorString(ie));
-                return PEM_E_HIP;
+                plan->warm = false;
+            } else {
+                graphed = true;
             }
-            plan->graph_gen = pem::alloc_generation();
-        }
-        PEM_HIP(hipGraphLaunch(plan->graph_exec, ctx->stream));
-        graphed = true;
-        int hf[NUM_FLAGS];
-        PEM_TRY(read_flags(ctx, hf));
-        if (hf[FLAG_CAPACITY]) {
-            set_error("pem_spgemm: a replayed pass computed sizes that differ from the captured ones");
-            return PEM_E_STATE;
-        }
-    } else {
-    PEM_TRY(step1_impl(ctx, plan, true));
-    PEM_TRY(step2_impl(ctx, plan));
-    PEM_TRY(step3_impl(ctx, plan));
-    if (plan->warm_pass) {
-        // repeat pass: the host never waited for P / T_C / C_nnz; check on the device that they are what it assumed
-        launch_verify();
-        int hf[NUM_FLAGS];
-        PEM_TRY(read_flags(ctx, hf));   // the pass's one synchronisation
-        if (hf[FLAG_CAPACITY]) {        // cannot happen while A and B are immutable; recover by a full pass
-            plan->warm = false;
-            PEM_TRY(step1_impl(ctx, plan, false));
-            PEM_TRY(step2_impl(ctx, plan));
-            PEM_TRY(step3_impl(ctx, plan));
         }
     }
+    if (!graphed) {
+        PEM_TRY(step1_impl(ctx, plan, true));
+        PEM_TRY(step2_impl(ctx, plan));
+        PEM_TRY(step3_impl(ctx, plan));
+        if (plan->warm_pass) {
+            // repeat pass: the host never waited for P / T_C / C_nnz; check on the device that they are what it assumed
+            launch_verify();
+            int hf[NUM_FLAGS];
+            PEM_TRY(read_flags(ctx, hf));   // the pass's one synchronisation
+            if (hf[FLAG_CAPACITY]) {        // cannot happen while A and B are immutable; recover by a full pass
+                plan->warm = false;
+                PEM_TRY(step1_impl(ctx, plan, false));
+                PEM_TRY(step2_impl(ctx, plan));
+                PEM_TRY(step3_impl(ctx, plan));
+            }
+        }
     }
     PEM_HIP(hipStreamSynchronize(ctx->stream));
     plan->warm = plan->pairs_ready && plan->state == 3;
