@@ -162,6 +162,7 @@ __global__ void s1_c_rowptr_kernel(const int *__restrict__ c_rowidx, long long n
 // compacted into the reference layout once the per-row tile counts have been scanned.
 // ------------------------------------------------------------------------------------------
 constexpr int S1_CAP0 = 512, S1_CAP1 = 2048, S1_CAP2 = 8192, S1_CAP3 = 32768;
+constexpr int S1_COARSE = 512;   // 64-product blocks indexed per row (covers the 32768 products a 15-bit index field allows)
 
 __global__ void s1_reset_kernel(int *__restrict__ flags, int *__restrict__ bin_count, long long *__restrict__ scalars,
                                 int *__restrict__ pairs_offset, int *__restrict__ row_tc, int mt)
@@ -307,7 +308,10 @@ struct S1Row {
     KeyT *keys;
     const int *roff, *rbs;
     const unsigned *rco;           // occupied columns of every A tile of the row (pruning)
-    bool staged;
+    const int *cstart;             // A tile holding product 64*c, for every 64th product (rows of up to 32768 products)
+    bool staged, coarse;
+    // (the one-wave bin has few A tiles per row: its search is short)
+    static constexpr bool COARSE_OK = THREADS >= 256;
     int R, a0, a1, p0, n, a_lo, prune;
     const int *a_tile_colidx, *aprod_off, *b_tile_rowptr, *b_tile_colidx;
     const uint32_t *a_occ, *b_occ;
@@ -322,7 +326,12 @@ struct S1Row {
         int ar;
         r.acol = 0xFFFFu;
         if (staged) {
-            ar = s1_find_a(roff, 0, R, q);
+            if (COARSE_OK && coarse) {   // a short walk from the tile of the 64-product block instead of a log2(R)-step search
+                ar = cstart[q >> 6];
+                while (roff[ar + 1] <= q) ++ar;
+            } else {
+                ar = s1_find_a(roff, 0, R, q);
+            }
             r.b = rbs[ar] + (q - roff[ar]);
             if (want_acol) r.acol = rco[ar];
             ar += a0;
@@ -422,20 +431,18 @@ struct S1Row {
         const int e0 = wave * rpw * 64 + lane;
         unsigned *myhist = hist + wave * 256;
         for (int shift = 0; shift < key_bits; shift += 8) {
-            KeyT k[EPT];
-#pragma unroll
-            for (int r = 0; r < EPT; ++r) k[r] = (r < rpw && e0 + r * 64 < n) ? keys[e0 + r * 64] : KeyT(0);
             for (int x = tid; x < WAVES * 256; x += THREADS) hist[x] = 0;
             __syncthreads();
-            // digit counts: one LDS atomic per key, except where the whole round holds one digit (the product-index
-            // bits of neighbouring products, already grouped columns) -- 64 atomics on one counter serialise, so
-            // there the first lane adds the round's population instead
+            // digit counts (keys read straight from LDS: they are only held in registers for the scatter below, which
+            // keeps 32 key registers from living across the scan).  One LDS atomic per key, except where the whole
+            // round holds one digit (the product-index bits of neighbouring products, already grouped columns) -- 64
+            // atomics on one counter serialise, so there the first lane adds the round's population instead
 #pragma unroll
             for (int r = 0; r < EPT; ++r) {
                 const bool valid = r < rpw && e0 + r * 64 < n;
                 const unsigned long long vm = __ballot(valid);
                 if (vm != 0) {                             // wave-uniform
-                    const unsigned d = (unsigned)(k[r] >> shift) & 255u;
+                    const unsigned d = valid ? (unsigned)(keys[e0 + r * 64] >> shift) & 255u : 0u;
                     const unsigned d0 = (unsigned)__shfl((int)d, __builtin_ctzll(vm), 64);
                     if (__ballot(valid && d != d0) == 0) {
                         if (lane == 0) myhist[d0] += (unsigned)__popcll(vm);
@@ -469,7 +476,10 @@ struct S1Row {
                     ex += (int)v[j];
                 }
             }
-            __syncthreads();
+            KeyT k[EPT];
+#pragma unroll
+            for (int r = 0; r < EPT; ++r) k[r] = (r < rpw && e0 + r * 64 < n) ? keys[e0 + r * 64] : KeyT(0);
+            __syncthreads();   // counters scanned, and every key is in a register before the first one is overwritten
 #pragma unroll
             for (int r = 0; r < EPT; ++r) {
                 if (r < rpw) {                             // wave-uniform
@@ -551,6 +561,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
     __shared__ unsigned rco[RCAP];     // occupied columns of that A tile
     __shared__ int wsum[THREADS / 64];
     __shared__ int s_cnt;
+    constexpr bool COARSE = S1Row<KeyT, CAP, QB, THREADS, RCAP>::COARSE_OK;
+    __shared__ int cstart[COARSE ? S1_COARSE : 1];
     __shared__ unsigned radix_hist[CAP > 8192 ? (THREADS / 64) * 256 : 1];   // digit counters of the radix sort (largest bin)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -592,6 +604,15 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
                     rbs[x] = b_tile_rowptr[a_tile_colidx[a_lo + row.a0 + x]];
                     rco[x] = a_occ[a_lo + row.a0 + x] & 0xFFFFu;
                 }
+            }
+        }
+        row.cstart = cstart;
+        row.coarse = COARSE && row.staged && row.n <= 64 * S1_COARSE;
+        if (row.coarse) {
+            __syncthreads();
+            for (int x = tid; x < row.R; x += THREADS) {      // every 64-product block start inside this A tile's range
+                const int lo = roff[x], hi = roff[x + 1];
+                for (int c = (lo + 63) >> 6; (c << 6) < hi; ++c) cstart[c] = x;
             }
         }
         __syncthreads();
