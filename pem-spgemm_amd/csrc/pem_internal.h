@@ -202,6 +202,7 @@ struct pem_cplan {
     mutable bool c_rowidx_valid = false;
     pem::DevBuf pairs_offset, pairs_a, pairs_b;
     pem::DevBuf c_mask, c_tile_nnz_ptr, c_rowcolidx, c_vals;
+    pem::DevBuf s3_chunk_tile;         // first C tile of every S3_CHUNK-entry chunk of C (written by step 2d for step 3's waves)
     mutable pem::DevBuf c_rowptr;      // Ctiles_rowPtr: materialised on demand from c_mask (nothing on the default path reads it)
     mutable bool c_rowptr_valid = false;
     // step-1 products kept for step 2 (expanded pair ids + the sorted permutation)

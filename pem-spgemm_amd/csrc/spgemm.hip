@@ -966,16 +966,24 @@ __global__ void __launch_bounds__(256) s2_crowptr_kernel(const uint32_t *__restr
     *reinterpret_cast<uint4 *>(c_rowptr + 16 * t) = make_uint4(rp[0], rp[1], rp[2], rp[3]);
 }
 
+constexpr int S3_CHUNK = 256;   // = S3_EPW below: C entries one wave of step 3 takes
 // a12 (spgemm.cu:582-587): packed (r<<4|c) bytes, one C tile per lane
 __global__ void __launch_bounds__(256) s2_crowcol_wide_kernel(const uint32_t *__restrict__ c_mask, const int *__restrict__ c_tile_nnz_ptr,
-                                                              long long ntc, uint8_t *__restrict__ c_rowcolidx)
+                                                              long long ntc, uint8_t *__restrict__ c_rowcolidx, int *__restrict__ chunk_tile)
 {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntc) return;
     const uint4 M0 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t);
     const uint4 M1 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t + 4);
     const unsigned w[8] = {M0.x, M0.y, M0.z, M0.w, M1.x, M1.y, M1.z, M1.w};
-    uint8_t *dst = c_rowcolidx + c_tile_nnz_ptr[t];
+    const int off = c_tile_nnz_ptr[t];
+    {   // step 3 deals C entries in chunks of S3_CHUNK: note the tile every chunk starts in (saves its waves a search)
+        int nnz_t = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nnz_t += __popc(w[q]);
+        for (int ch = (off + S3_CHUNK - 1) / S3_CHUNK; ch * S3_CHUNK < off + nnz_t; ++ch) chunk_tile[ch] = (int)t;
+    }
+    uint8_t *dst = c_rowcolidx + off;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         unsigned m = w[q] >> 16;              // row 2q
@@ -999,38 +1007,26 @@ __global__ void __launch_bounds__(256) s2_crowcol_wide_kernel(const uint32_t *__
 // row record (mask | rowptr<<16), one of B's transposed mask; per product one B row record and
 // the two operand values.  Pairs ascend in k-tile, bits ascend, one fma per product: the same
 // chain as the oracle.
-constexpr int S3_EPW = 256;   // C entries per wave
+constexpr int S3_EPW = S3_CHUNK;   // C entries per wave
 template <typename VT>
 __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b, long long ntc,
     const int *__restrict__ c_tile_nnz_ptr, long long nnz_c, const uint8_t *__restrict__ c_rowcolidx, VT *__restrict__ c_vals,
     const int *__restrict__ a_nnz_ptr, const VT *__restrict__ a_vals, const uint32_t *__restrict__ a_rec,
-    const int *__restrict__ b_nnz_ptr, const VT *__restrict__ b_vals_t, const uint32_t *__restrict__ b_rec_t)
+    const int *__restrict__ b_nnz_ptr, const VT *__restrict__ b_vals_t, const uint32_t *__restrict__ b_rec_t,
+    const int *__restrict__ chunk_tile)
 {
     // Work is dealt by ENTRIES, S3_EPW per wave, so hub rows (tiles with many entries and pairs) cannot pile
-    // up in one wave.  The wave finds its first tile with a 64-ary search (one gather + ballot per level),
-    // then walks the tiles 64 at a time: their value offsets and pair ranges sit one per lane in registers,
-    // and the entry -> tile lookup is a 6-step shuffle search with no memory traffic.
+    // up in one wave.  The wave starts at the tile its first entry lies in (noted by step 2d; a 64-ary search over
+    // the tile offsets -- three dependent gathers per wave -- before that), then walks the tiles 64 at a time:
+    // their value offsets and pair ranges sit one per lane in registers, and the entry -> tile lookup is a 6-step
+    // shuffle search with no memory traffic.
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long eb = wave * S3_EPW;
     if (eb >= nnz_c) return;
     const int e_lo = (int)eb, e_hi = (int)(eb + S3_EPW < nnz_c ? eb + S3_EPW : nnz_c);
-    // largest tile t with c_tile_nnz_ptr[t] <= e_lo
-    long long lo = 0, hi = ntc;   // invariant: ptr[lo] <= e_lo, answer in [lo, hi)
-    while (hi - lo > 64) {
-        const long long step = (hi - lo + 63) >> 6;
-        const long long idx = lo + lane * step;
-        const bool le = idx < hi && c_tile_nnz_ptr[idx] <= e_lo;
-        const int k = __popcll(__ballot(le));          // monotone: the first k probes are <= e_lo (k >= 1)
-        const long long nlo = lo + (long long)(k - 1) * step;
-        hi = nlo + step < hi ? nlo + step : hi;
-        lo = nlo;
-    }
-    {
-        const bool le = lo + lane < hi && c_tile_nnz_ptr[lo + lane] <= e_lo;
-        lo += __popcll(__ballot(le)) - 1;
-    }
+    const long long lo = chunk_tile[wave];   // the tile entry e_lo lies in (noted by s2_crowcol_wide_kernel)
     for (long long t0 = lo; t0 < ntc; t0 += 64) {
         const long long tl = t0 + lane < ntc ? t0 + lane : ntc - 1;
         const int my_off = (t0 + lane < ntc) ? c_tile_nnz_ptr[tl] : 0x7FFFFFFF;   // value offset of tile t0+lane
@@ -1676,11 +1672,12 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
     }
     p->nnz_c = nnzc;
     PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
+    PEM_TRY(p->s3_chunk_tile.reserve(sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)));
     PEM_TRY(p->c_vals.reserve((size_t)A->value_bytes * ((size_t)nnzc + 1)));
     if (ntc > 0) {
         if (wide)
             PEM_LAUNCH(ctx, s2_crowcol_wide_kernel, grid_for(ntc, 256), 256, p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
-                       p->c_rowcolidx.as<uint8_t>());
+                       p->c_rowcolidx.as<uint8_t>(), p->s3_chunk_tile.as<int>());
         else {   // the 16-lanes-per-tile baseline writes Ctiles_rowPtr as it goes, like the reference (spgemm.cu:579-580)
             PEM_TRY(p->c_rowptr.reserve(16 * (ntc + 1)));
             PEM_LAUNCH(ctx, s2_crowcol_kernel, grid_for(ntc * 16, 256), 256, p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
@@ -1712,7 +1709,8 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
             PEM_LAUNCH(ctx, s3_accumulate_wide_kernel<VT>, grid_for(((size_t)p->nnz_c + S3_EPW - 1) / S3_EPW * 64, 256), 256,                  \
                        p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),     \
                        (long long)p->nnz_c, p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),     \
-                       A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>());               \
+                       A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                \
+                       p->s3_chunk_tile.as<int>());                                                                                            \
         else                                                                                                                                   \
             PEM_LAUNCH(ctx, s3_accumulate_kernel<VT>, grid_for(ntc * 16, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(),           \
                        p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(),    \
