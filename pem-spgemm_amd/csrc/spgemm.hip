@@ -387,28 +387,6 @@ struct S1Row {
         __syncthreads();
         return nlive;
     }
-    // more than 16 keys per thread: sort in LDS (a register-resident sort of 32 keys per thread spills)
-    __device__ __forceinline__ void sort_lds(const int tid, const int nlive) const
-    {
-        int npad = 2;
-        while (npad < nlive) npad <<= 1;
-        for (int x = nlive + tid; x < npad; x += THREADS) keys[x] = ~KeyT(0);
-        __syncthreads();
-        for (int kk = 2; kk <= npad; kk <<= 1) {
-            for (int jj = kk >> 1; jj > 0; jj >>= 1) {
-                for (int t = tid; t < (npad >> 1); t += THREADS) {
-                    const int lo = 2 * t - (t & (jj - 1)), hi = lo + jj;
-                    const bool up = (lo & kk) == 0;
-                    const KeyT x = keys[lo], y = keys[hi];
-                    if ((x > y) == up) {
-                        keys[lo] = y;
-                        keys[hi] = x;
-                    }
-                }
-                __syncthreads();
-            }
-        }
-    }
     // lanes of the wave holding the same 8-bit digit as this one (among the valid lanes)
     static __device__ __forceinline__ unsigned long long match_digit(const bool valid, const unsigned d)
     {
@@ -627,12 +605,10 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
             row.template sort_regs<2, LOGT>(tid);
         else if (nl <= THREADS * 4)
             row.template sort_regs<4, LOGT>(tid);
-        else if (nl <= THREADS * 8)
+        else if (EMAX == 8 || nl <= THREADS * 8)      // a bin never holds more than CAP = THREADS * EMAX live keys
             row.template sort_regs<8, LOGT>(tid);
-        else if constexpr (EMAX == 32 && THREADS == 1024)
+        else if constexpr (EMAX == 32)
             row.template sort_radix<32>(tid, nl, radix_hist, wsum, key_bits);
-        else
-            row.sort_lds(tid, nl);
         // stream out the live products (the dead ones sorted behind them): sorted pairs, and per distinct tile
         // column (C tile) its column + first pair; output positions count live products only
         S1_DBG_MARK(2);
