@@ -705,21 +705,20 @@ __global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint3
     if (s == 0) row_tc[i] = headx[rs + ni] - headx[rs];
 }
 
-// row-local scratch -> reference layout (_C_tileRowIdx/_C_tileColIdx, spgemm.cu:378-379; pair offsets :484)
-// One wave per tile row: the row knows where its tiles go (c_rowptr[i]) and where its scratch
-// lives (its first pair), so the copy is two coalesced streams and needs no search.
+// row-local scratch -> reference layout (_C_tileColIdx, spgemm.cu:379; pair offsets :484)
+// One block per tile row: the row knows where its tiles go (c_rowptr[i]) and where its scratch lives (its first
+// pair), so the copy is two coalesced streams and needs no search.  (One WAVE per row was as fast on a whole matrix,
+// where the kernel is bandwidth-bound, but left a 1/8 slice -- 8 k rows of ~300 tiles -- latency-bound: 34 us.)
 __global__ void __launch_bounds__(256) s1_compact_kernel(const int *__restrict__ c_rowptr, int mt, long long ntc, int tr_lo,
                                                          const int *__restrict__ a_tile_rowptr, int a_lo, const int *__restrict__ aprod_off,
                                                          const int *__restrict__ scratch_col, const int *__restrict__ scratch_off, int npairs,
                                                          int *__restrict__ c_colidx, int *__restrict__ pairs_offset)
 {
-    const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int i = wave; i < mt; i += nwaves) {
+    for (int i = blockIdx.x; i < mt; i += gridDim.x) {
         const int t0 = c_rowptr[i], cnt = c_rowptr[i + 1] - t0;
         if (cnt == 0) continue;
         const int p0 = aprod_off[a_tile_rowptr[tr_lo + i] - a_lo];
-        for (int r = lane; r < cnt; r += 64) {
+        for (int r = threadIdx.x; r < cnt; r += blockDim.x) {
             c_colidx[t0 + r] = scratch_col[p0 + r];
             pairs_offset[t0 + r] = p0 + scratch_off[p0 + r];
         }
@@ -1582,7 +1581,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         const size_t ntc = (size_t)TC;
         PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
         PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
-        PEM_LAUNCH(ctx, s1_compact_kernel, grid_for((size_t)mt * 64, 256), 256, p->c_tile_rowptr.as<int>(), mt, (long long)TC, p->tr_lo,
+        PEM_LAUNCH(ctx, s1_compact_kernel, (unsigned)mt, 256, p->c_tile_rowptr.as<int>(), mt, (long long)TC, p->tr_lo,
                    A->tile_rowptr.as<int>(), p->a_lo, p->lprod_off.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), (int)P,
                    p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>());
         p->pairs_ready = true;
