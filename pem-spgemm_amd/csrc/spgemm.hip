@@ -314,6 +314,7 @@ struct S1Row {
     bool staged, coarse;
     // (the one-wave bin has few A tiles per row: its search is short)
     static constexpr bool COARSE_OK = THREADS >= 256;
+    static constexpr bool ORDERED = THREADS == 1024;   // live keys compacted in product order (see expand_compact)
     int R, a0, a1, p0, n, a_lo, prune;
     const int *a_tile_colidx, *aprod_off, *b_tile_rowptr, *b_tile_colidx;
     const uint32_t *a_occ, *b_occ;
@@ -356,27 +357,64 @@ struct S1Row {
     // expand all n products of the row, keep the live ones: their keys are packed into keys[0..nlive) in
     // arbitrary order (ballot + one LDS atomic per wave and chunk) -- the sort that follows fixes the order,
     // and only live keys get sorted.  Returns nlive; keys[nlive..npad_to) are set to the padding key.
-    __device__ __forceinline__ int expand_compact(const int tid, int *s_cnt, int npad_to_mult) const
+    __device__ __forceinline__ int expand_compact(const int tid, int *s_cnt, int npad_to_mult, int *ordcnt) const
     {
-        const int lane = tid & 63;
+        const int lane = tid & 63, wave = tid >> 6;
         const unsigned long long lt = (1ull << lane) - 1ull;
         // four chunks per trip: their table searches and B-side gathers are independent and overlap; the
-        // compaction (ballot + one LDS atomic per wave and chunk) follows once the keys are in registers
-        constexpr int U = 4;
-        for (int q0 = 0; q0 < n; q0 += U * THREADS) {
-            KeyT key[U];
+        // compaction follows once the keys are in registers
+        constexpr int U = ORDERED && CAP <= 8192 ? 2 : 4;   // (the 8192-key bin has 64 registers per lane: two chunks in flight)
+        if constexpr (ORDERED) {
+            // 16-wave bins keep the live keys in PRODUCT ORDER (chunk, wave, lane ascending), so that a stable sort on
+            // the tile column alone finishes the job: every (chunk, wave) posts its live count, a barrier, and each
+            // wave adds up the counts in front of it (at most 64 LDS reads)
+            constexpr int WAVES = THREADS / 64;
+            int total = 0;
+            for (int q0 = 0; q0 < n; q0 += U * THREADS) {
+                KeyT key[U];
+                unsigned long long bal[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) key[u] = product_key(q0 + u * THREADS + tid);
+                for (int u = 0; u < U; ++u) key[u] = product_key(q0 + u * THREADS + tid);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool live = key[u] != ~KeyT(0);
-                const unsigned long long bal = __ballot(live);
-                if (bal) {
-                    int base = 0;
-                    const int leader = __builtin_ctzll(bal);
-                    if (lane == leader) base = atomicAdd(s_cnt, __popcll(bal));
-                    base = __shfl(base, leader, 64);
-                    if (live) keys[base + __popcll(bal & lt)] = key[u];
+                for (int u = 0; u < U; ++u) {
+                    bal[u] = __ballot(key[u] != ~KeyT(0));
+                    if (lane == 0) ordcnt[u * WAVES + wave] = __popcll(bal[u]);
+                }
+                __syncthreads();
+                int c = lane < U * WAVES ? ordcnt[lane] : 0;          // U * WAVES = 64 counts, one per lane
+                int inc = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(inc, d, 64);
+                    if (lane >= d) inc += o;
+                }
+                const int trip_total = __shfl(inc, 63, 64);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int base = total + __shfl(inc - c, u * WAVES + wave, 64);
+                    if (key[u] != ~KeyT(0)) keys[base + __popcll(bal[u] & lt)] = key[u];
+                }
+                total += trip_total;
+                __syncthreads();                                      // the counts are re-posted by the next trip
+            }
+            if (tid == 0) *s_cnt = total;
+        } else {
+            // ballot + one LDS atomic per wave and chunk: arbitrary order, the full-key sort that follows fixes it
+            for (int q0 = 0; q0 < n; q0 += U * THREADS) {
+                KeyT key[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) key[u] = product_key(q0 + u * THREADS + tid);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool live = key[u] != ~KeyT(0);
+                    const unsigned long long bal = __ballot(live);
+                    if (bal) {
+                        int base = 0;
+                        const int leader = __builtin_ctzll(bal);
+                        if (lane == leader) base = atomicAdd(s_cnt, __popcll(bal));
+                        base = __shfl(base, leader, 64);
+                        if (live) keys[base + __popcll(bal & lt)] = key[u];
+                    }
                 }
             }
         }
@@ -401,7 +439,8 @@ struct S1Row {
         }
         return m;
     }
-    template <int EPT> __device__ __forceinline__ void sort_radix(const int tid, const int n, unsigned *hist, int *wsum, const int key_bits) const
+    template <int EPT> __device__ __forceinline__ void sort_radix(const int tid, const int n, unsigned *hist, int *wsum, const int first_bit,
+                                                                  const int key_bits) const
     {
         static_assert(THREADS == 1024, "sized for 16 waves: 4096 counters, four per thread in the scan");
         constexpr int WAVES = THREADS / 64;
@@ -410,7 +449,7 @@ struct S1Row {
         const int rpw = (n + THREADS - 1) / THREADS;   // rounds per wave, <= EPT
         const int e0 = wave * rpw * 64 + lane;
         unsigned *myhist = hist + wave * 256;
-        for (int shift = 0; shift < key_bits; shift += 8) {
+        for (int shift = first_bit; shift < key_bits; shift += 8) {
             for (int x = tid; x < WAVES * 256; x += THREADS) hist[x] = 0;
             __syncthreads();
             // digit counts (keys read straight from LDS: they are only held in registers for the scatter below, which
@@ -473,6 +512,7 @@ struct S1Row {
                         if (rank == 0) myhist[d] = base + (unsigned)__popcll(m);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);   // rounds are serial through myhist anyway: keep their ballots from piling up in registers
             }
             __syncthreads();
         }
@@ -543,7 +583,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
     __shared__ int s_cnt;
     constexpr bool COARSE = S1Row<KeyT, CAP, QB, THREADS, RCAP>::COARSE_OK;
     __shared__ int cstart[COARSE ? S1_COARSE : 1];
-    __shared__ unsigned radix_hist[CAP > 8192 ? (THREADS / 64) * 256 : 1];   // digit counters of the radix sort (largest bin)
+    __shared__ unsigned radix_hist[THREADS == 1024 ? (THREADS / 64) * 256 : 1];   // digit counters of the radix sort (16-wave bins)
+    __shared__ int ordcnt[64];                                                   // live counts per (chunk, wave) of the ordered compaction
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
 #ifdef PEM_S1_DEBUG
@@ -599,18 +640,20 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
         S1_DBG_MARK(0);
         // expand the row's products into (tile col, product index) keys -- live ones only -- and sort them; equal
         // tile columns stay in product (= ascending k) order because the index is part of the key
-        const int nl = row.expand_compact(tid, &s_cnt, THREADS);
+        const int nl = row.expand_compact(tid, &s_cnt, THREADS, ordcnt);
         S1_DBG_MARK(1);
-        if (nl <= THREADS)
+        if constexpr (THREADS == 1024) {
+            // 16-wave bins (more than 2048 live keys): the keys sit in product order, so a STABLE radix sort on the tile
+            // column bits alone (2 passes for up to 65536 tile columns) replaces a bitonic network over the whole key
+            row.template sort_radix<EMAX>(tid, nl, radix_hist, wsum, QB, key_bits);
+        } else if (nl <= THREADS)
             row.template sort_regs<1, LOGT>(tid);
         else if (nl <= THREADS * 2)
             row.template sort_regs<2, LOGT>(tid);
         else if (nl <= THREADS * 4)
             row.template sort_regs<4, LOGT>(tid);
-        else if (EMAX == 8 || nl <= THREADS * 8)      // a bin never holds more than CAP = THREADS * EMAX live keys
-            row.template sort_regs<8, LOGT>(tid);
-        else if constexpr (EMAX == 32)
-            row.template sort_radix<32>(tid, nl, radix_hist, wsum, key_bits);
+        else
+            row.template sort_regs<8, LOGT>(tid);             // a bin never holds more than CAP = THREADS * EMAX live keys
         // stream out the live products (the dead ones sorted behind them): sorted pairs, and per distinct tile
         // column (C tile) its column + first pair; output positions count live products only
         S1_DBG_MARK(2);
