@@ -363,7 +363,7 @@ struct S1Row {
         const unsigned long long lt = (1ull << lane) - 1ull;
         // four chunks per trip: their table searches and B-side gathers are independent and overlap; the
         // compaction follows once the keys are in registers
-        constexpr int U = ORDERED && CAP <= 8192 ? 2 : 4;   // (the 8192-key bin has 64 registers per lane: two chunks in flight)
+        constexpr int U = 4;
         if constexpr (ORDERED) {
             // 16-wave bins keep the live keys in PRODUCT ORDER (chunk, wave, lane ascending), so that a stable sort on
             // the tile column alone finishes the job: every (chunk, wave) posts its live count, a barrier, and each
