@@ -156,12 +156,14 @@ __global__ void s1_c_rowptr_kernel(const int *__restrict__ c_rowidx, long long n
 // ------------------------------------------------------------------------------------------
 // step 1, row-local form (default).  The products of one tile row of A only ever meet
 // products of the same row, so the grouping by C tile is a per-row sort on the tile column:
-// one workgroup expands the row's products into LDS, bitonic-sorts (tile col, product index)
-// keys there, and streams the sorted pair list out once -- no global sort passes.  Rows are
-// binned by their product count (<=128: one wave, <=1024: 256 threads, <=8192: 1024 threads);
-// larger rows take the global expand/radix-sort path above.  C tile columns and per-tile pair
-// offsets go to row-local scratch (a row has at most as many C tiles as products) and are
-// compacted into the reference layout once the per-row tile counts have been scanned.
+// one workgroup expands the row's live products into LDS as (tile col, product index) keys,
+// sorts them there and streams the sorted pair list out once -- no global sort passes.  Rows
+// are binned by their LIVE product count: <=512 one wave and <=2048 four waves (bitonic network
+// in registers), <=8192 and <=32768 sixteen waves (keys kept in product order + a stable LDS
+// radix sort on the column bits); larger rows take the global expand/radix-sort path above.
+// C tile columns and per-tile pair offsets go to row-local scratch (a row has at most as many
+// C tiles as products) and are compacted into the reference layout once the per-row tile
+// counts have been scanned.
 // ------------------------------------------------------------------------------------------
 constexpr int S1_CAP0 = 512, S1_CAP1 = 2048, S1_CAP2 = 8192, S1_CAP3 = 32768;
 constexpr int S1_COARSE = 512;   // 64-product blocks indexed per row (covers the 32768 products a 15-bit index field allows)
@@ -234,9 +236,9 @@ __device__ __forceinline__ int s1_find_a(const int *__restrict__ off, int lo, in
     return lo;
 }
 
-// Bitonic sort of THREADS*EPT keys held EPT per thread (element e = m*THREADS + tid).  Strides
-// below 64 exchange by wave shuffle, strides >= THREADS are register-local, only the strides in
-// [64, THREADS) go through LDS -- 5 of the 45 stages at 512 keys.  Ends with the keys in `lds`.
+// Bitonic sort of THREADS*EPT keys held EPT per thread in the blocked layout (element e = tid*EPT + m, see
+// s1_bitonic_regs): the smallest strides are register-local, the next six wave shuffles, the rest through LDS.
+// Ends with the keys in `lds`.
 template <typename KeyT> __device__ __forceinline__ KeyT s1_shfl_xor(KeyT v, int mask);
 template <> __device__ __forceinline__ uint32_t s1_shfl_xor<uint32_t>(uint32_t v, int mask) { return (uint32_t)__shfl_xor((int)v, mask, 64); }
 template <> __device__ __forceinline__ uint64_t s1_shfl_xor<uint64_t>(uint64_t v, int mask)
