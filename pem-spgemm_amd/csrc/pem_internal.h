@@ -196,6 +196,7 @@ struct pem_cplan {
     int tr_lo = 0, tr_hi = 0;
     int a_lo = 0, a_hi = 0;            // A tile id range of the slice
     int state = 0;                     // 0 created, 1 step1 done, 2 step2 done, 3 step3 done
+    int opt_prune = 1, opt_key64 = 0, opt_xlcap = 0;   // PEM_PRUNE / PEM_S1_FORCE_KEY64 / PEM_S1_XLCAP, latched at plan creation
     int64_t ntiles_c = 0, npairs = 0, nnz_c = 0;
     pem::DevBuf c_tile_rowptr, c_tile_colidx;
     mutable pem::DevBuf c_tile_rowidx; // _C_tileRowIdx: on demand from c_tile_rowptr on the row-local path (no reader there)
@@ -214,6 +215,9 @@ struct pem_cplan {
     // row-local step 1
     pem::DevBuf row_list, bin_count, xl_base, xl_rowstart, scratch_col, scratch_off;
     bool pairs_ready = false;          // step 1 already wrote pairs_a / pairs_b
+    bool wide = true;                  // step 2 ran the fused kernel (step 3 then runs entry-per-lane); false: 16-lanes-per-tile baseline
+    bool compact_valid = false;        // c_tile_colidx / pairs_offset hold the dense layout (else: row-local scratch, see ensure_compact)
+    pem::DevBuf lb_state;              // step 2 look-back: one 64-bit word per 256-slot block + the ticket counter behind them
     // sizes of the last complete pass on this plan.  A and B are immutable, so a repeat pass has the same
     // sizes: it skips the three host read-backs and a device-side check compares them at the end instead.
     hipGraphExec_t graph_exec = nullptr;   // PEM_GRAPH=1: the captured warm pass

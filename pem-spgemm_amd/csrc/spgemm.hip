@@ -183,7 +183,7 @@ __global__ void s1_reset_kernel(int *__restrict__ flags, int *__restrict__ bin_c
 
 __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int mt, int a_lo,
                                                           const int *__restrict__ aprod_off, const int *__restrict__ lprod_off, int cap3,
-                                                          int qcap, int *__restrict__ row_list,
+                                                          int qcap, int xlcap, int *__restrict__ row_list,
                                                           int *__restrict__ bin_count, int *__restrict__ xl_base, int *__restrict__ row_tc)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
         row_tc[i] = 0;
     }
     // bins by LIVE products (what gets sorted); the key's index field must still hold every product of the row
-    const int bin = nl == 0 ? -1 : n > qcap ? 4 : nl <= S1_CAP0 ? 0 : nl <= S1_CAP1 ? 1 : nl <= S1_CAP2 ? 2 : nl <= cap3 ? 3 : 4;
+    const int bin = nl == 0 ? -1 : (n > qcap || nl > xlcap) ? 4 : nl <= S1_CAP0 ? 0 : nl <= S1_CAP1 ? 1 : nl <= S1_CAP2 ? 2 : nl <= cap3 ? 3 : 4;
     // slots by ballot + prefix popcount inside a wave, one LDS atomic per wave and bin inside the block, ONE global
     // atomic per block and bin (order inside a bin is irrelevant): 4 k wave-level atomics on four counters serialised
     // for ~20 us of a 33 us kernel
@@ -691,11 +691,17 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
                 if (head) {
                     int rank = base + woff + __popcll(bal & lt);
                     scratch_col[lp0 + rank] = j;
-                    scratch_off[lp0 + rank] = s;
+                    scratch_off[lp0 + rank] = lp0 + s;
                 }
             }
             base += tot;
             __syncthreads();
+        }
+        // the row's slots behind its last tile start no tile: marked, and holding the end of the row's pairs (step 2 reads
+        // a tile's pair range as [scratch_off[slot], scratch_off[slot + 1]))
+        for (int x = base + tid; x < nlive; x += THREADS) {
+            scratch_col[lp0 + x] = -1;
+            scratch_off[lp0 + x] = lp0 + nlive;
         }
         if (tid == 0) row_tc[i] = base;
         S1_DBG_MARK(3);
@@ -744,12 +750,17 @@ __global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint3
     pairs_a[p0 + s] = prod_a[o];
     pairs_b[p0 + s] = prod_b[o];
     int hx = headx[x];
+    const int ntiles_row = headx[rs + ni] - headx[rs];
     if (headx[x + 1] != hx) {
         int rank = hx - headx[rs];
         scratch_col[p0 + rank] = j;
-        scratch_off[p0 + rank] = s;
+        scratch_off[p0 + rank] = p0 + s;
     }
-    if (s == 0) row_tc[i] = headx[rs + ni] - headx[rs];
+    if (s >= ntiles_row) {   // slots behind the row's last tile (see s1_rowsort_kernel)
+        scratch_col[p0 + s] = -1;
+        scratch_off[p0 + s] = p0 + ni;
+    }
+    if (s == 0) row_tc[i] = ntiles_row;
 }
 
 // row-local scratch -> reference layout (_C_tileColIdx, spgemm.cu:379; pair offsets :484)
@@ -767,7 +778,7 @@ __global__ void __launch_bounds__(256) s1_compact_kernel(const int *__restrict__
         const int p0 = aprod_off[a_tile_rowptr[tr_lo + i] - a_lo];
         for (int r = threadIdx.x; r < cnt; r += blockDim.x) {
             c_colidx[t0 + r] = scratch_col[p0 + r];
-            pairs_offset[t0 + r] = p0 + scratch_off[p0 + r];
+            pairs_offset[t0 + r] = scratch_off[p0 + r];
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) pairs_offset[ntc] = npairs;
@@ -913,57 +924,205 @@ __global__ void __launch_bounds__(256) s3_accumulate_kernel(
 // unit of work: one C tile per lane for the masks (two 16-byte loads per operand tile, the
 // 16x16 boolean product in registers), one C entry per lane for the numeric step.
 // ------------------------------------------------------------------------------------------
-// a11 + the row-pointer half of a12 (spgemm.cu:499-550, 579-580): one C tile per lane.
-// Two rows share a dword (w[q] = row 2q | row 2q+1 << 16, the natural uint16 layout), so
-// ((Aw >> kk) & 0x00010001) * Brow(kk) ORs B's row kk into both rows at once.
-__global__ void __launch_bounds__(256) s2_cmask_wide_kernel(const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a,
-                                                            const int *__restrict__ pairs_b, long long ntc,
-                                                            const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks,
-                                                            uint32_t *__restrict__ c_mask, int *__restrict__ c_tile_nnz)
+// The boolean product of one tile pair, shared by the fused step-2 kernel: B's 16 row masks are parked in LDS
+// ([dword q][lane]; a lane only ever reads what it wrote itself -- same wave, program order -- so no barrier is
+// needed) and C row r |= OR_{kk in A row r} B row kk iterates over A's nonzeros only.  Two rows share a dword
+// (w[q] = row 2q | row 2q+1 << 16, the natural uint16 layout).
+__device__ __forceinline__ void s2_pair_mask(const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks, const int a,
+                                             const int b, unsigned (*bl)[256], const int tid, unsigned (&cw)[8])
 {
-    // B's 16 row masks of the lane's current pair, [dword q][lane]: a lane only ever reads what it
-    // wrote itself (same wave, program order), so no barrier is needed
-    __shared__ unsigned bl[8][256];
-    const int tid = threadIdx.x;
-    long long t = (long long)blockIdx.x * blockDim.x + tid;
-    if (t >= ntc) return;
-    const int p0 = pairs_offset[t], p1 = pairs_offset[t + 1];
-    unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // natural layout: cw[q] = row 2q | row 2q+1 << 16
-    for (int p = p0; p < p1; ++p) {
-        const int a = pairs_a[p], b = pairs_b[p];
-        const uint4 A0 = *reinterpret_cast<const uint4 *>(a_masks + 16 * (size_t)a);
-        const uint4 A1 = *reinterpret_cast<const uint4 *>(a_masks + 16 * (size_t)a + 8);
-        const uint4 B0 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)b);
-        const uint4 B1 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)b + 8);
-        bl[0][tid] = B0.x; bl[1][tid] = B0.y; bl[2][tid] = B0.z; bl[3][tid] = B0.w;
-        bl[4][tid] = B1.x; bl[5][tid] = B1.y; bl[6][tid] = B1.z; bl[7][tid] = B1.w;
-        const unsigned aw[8] = {A0.x, A0.y, A0.z, A0.w, A1.x, A1.y, A1.z, A1.w};
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            unsigned am = aw[q];            // bits 0-15: row 2q, bits 16-31: row 2q+1
-            unsigned acc = 0;
-            while (am) {                    // one iteration per nonzero of A in these two rows
-                const int bit = __builtin_ctz(am);
-                am &= am - 1;
-                const int kk = bit & 15;
-                const unsigned bwd = bl[kk >> 1][tid];            // rows kk&~1 (low half) and kk|1 (high half)
-                const unsigned brow = (kk & 1) ? (bwd >> 16) : (bwd & 0xFFFFu);
-                acc |= brow << (bit & 16);
-            }
-            cw[q] |= acc;
-        }
-    }
-    // reference packing: word q = (row 2q) << 16 | row 2q+1  (spgemm.cu:533-543)
-    unsigned out[8];
-    int run = 0;
+    const uint4 A0 = *reinterpret_cast<const uint4 *>(a_masks + 16 * (size_t)a);
+    const uint4 A1 = *reinterpret_cast<const uint4 *>(a_masks + 16 * (size_t)a + 8);
+    const uint4 B0 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)b);
+    const uint4 B1 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)b + 8);
+    bl[0][tid] = B0.x; bl[1][tid] = B0.y; bl[2][tid] = B0.z; bl[3][tid] = B0.w;
+    bl[4][tid] = B1.x; bl[5][tid] = B1.y; bl[6][tid] = B1.z; bl[7][tid] = B1.w;
+    const unsigned aw[8] = {A0.x, A0.y, A0.z, A0.w, A1.x, A1.y, A1.z, A1.w};
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        out[q] = (cw[q] << 16) | (cw[q] >> 16);   // rows 2q, 2q+1 swap halves
-        run += __popc(cw[q]);
+        unsigned am = aw[q];            // bits 0-15: row 2q, bits 16-31: row 2q+1
+        unsigned acc = 0;
+        while (am) {                    // one iteration per nonzero of A in these two rows
+            const int bit = __builtin_ctz(am);
+            am &= am - 1;
+            const int kk = bit & 15;
+            const unsigned bwd = bl[kk >> 1][tid];            // rows kk&~1 (low half) and kk|1 (high half)
+            const unsigned brow = (kk & 1) ? (bwd >> 16) : (bwd & 0xFFFFu);
+            acc |= brow << (bit & 16);
+        }
+        cw[q] |= acc;
     }
-    *reinterpret_cast<uint4 *>(c_mask + 8 * t) = make_uint4(out[0], out[1], out[2], out[3]);
-    *reinterpret_cast<uint4 *>(c_mask + 8 * t + 4) = make_uint4(out[4], out[5], out[6], out[7]);
-    c_tile_nnz[t] = run;
+}
+
+// (r<<4|c) bytes of one C tile from its masks in the natural layout (a12, spgemm.cu:582-587), row-major
+__device__ __forceinline__ void s2_emit_rowcol(const unsigned (&cw)[8], uint8_t *__restrict__ dst)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        unsigned m = cw[q] & 0xFFFFu;         // row 2q
+        while (m) {
+            const int c = __builtin_ctz(m);
+            m &= m - 1;
+            *dst++ = (uint8_t)(((2 * q) << 4) | c);
+        }
+        m = cw[q] >> 16;                      // row 2q+1
+        while (m) {
+            const int c = __builtin_ctz(m);
+            m &= m - 1;
+            *dst++ = (uint8_t)(((2 * q + 1) << 4) | c);
+        }
+    }
+}
+
+constexpr int S3_CHUNK = 256;   // = S3_EPW below: C entries one wave of step 3 takes
+
+// ------------------------------------------------------------------------------------------
+// Step 2 in ONE kernel (a10 offsets + a11 + a12, spgemm.cu:483-484, 499-550, 552-591) over the row-local
+// step-1 scratch.  Step 1 leaves, for every live product slot s in [0, P): scratch_col[s] = tile column of the
+// C tile whose pair list starts there (or -1: no tile starts in this slot), scratch_off[s] = first pair of
+// that tile (a gap slot holds the end of its row's pairs, so the end of any tile's pairs is scratch_off[s+1]).
+// A row's tiles sit at the front of the row's slot range in ascending column order, so the valid slots, read
+// in slot order, ARE the C tile list in the reference's order.  One slot per lane:
+//   mask      boolean product over the tile's pairs (two 16-byte loads per operand tile)
+//   position  the tile's index t and the offset of its entries are exclusive prefix sums over all earlier
+//             slots: block-local scan + decoupled look-back over the blocks' (tiles, entries) aggregates,
+//             packed into one 64-bit word per block so that one store publishes both consistently
+//   outputs   _C_tileColIdx[t], pairs offset[t], Ctiles_mask[8t..], perTileNnz offset[t], and -- when the
+//             entry total is known beforehand (repeat pass) -- the (r<<4|c) bytes and step 3's chunk index.
+// This replaces s1_compact + the C-tile scan + the mask kernel + the entry scan (3 launches) + the (r<<4|c)
+// kernel: the 32-byte masks are not re-read, the per-tile offsets are written once instead of written,
+// scanned and re-read.  Blocks take their slot range by a ticket, so a block only ever waits for blocks
+// that started before it (they are resident and never wait for a later one): the look-back cannot deadlock;
+// a poll budget turns any protocol failure into FLAG_CAPACITY instead of a hang.
+// ------------------------------------------------------------------------------------------
+constexpr unsigned long long LB_AGG = 1ull, LB_PREFIX = 2ull;   // status in bits 0-1; tiles in bits 2-32, entries in bits 33-63
+constexpr int LB_POLL_BUDGET = 1 << 22;
+
+template <bool WRITE_RC>
+__global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ scratch_col, const int *__restrict__ scratch_off, long long nslots,
+                                                       const int *__restrict__ pairs_a, const int *__restrict__ pairs_b,
+                                                       const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks,
+                                                       unsigned long long *lb_state, int *lb_ticket, long long cap_tiles, long long cap_nnz,
+                                                       int *__restrict__ c_colidx, int *__restrict__ pairs_offset, uint32_t *__restrict__ c_mask,
+                                                       int *__restrict__ c_tile_nnz_ptr, uint8_t *__restrict__ c_rowcolidx,
+                                                       int *__restrict__ chunk_tile, long long *__restrict__ d_scalars, int *__restrict__ flags)
+{
+    __shared__ unsigned bl[8][256];
+    __shared__ int s_ticket;
+    __shared__ int w_tiles[4], w_nnz[4];
+    __shared__ unsigned long long s_excl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_ticket = atomicAdd(lb_ticket, 1);
+    __syncthreads();
+    const int blk = s_ticket;
+    const long long s = (long long)blk * 256 + tid;
+    int col = -1, p0 = 0, p1 = 0;
+    if (s < nslots) {
+        col = scratch_col[s];
+        if (col >= 0) {
+            p0 = scratch_off[s];
+            p1 = s + 1 < nslots ? scratch_off[s + 1] : (int)nslots;
+        }
+    }
+    const bool valid = col >= 0;
+    unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // natural layout: cw[q] = row 2q | row 2q+1 << 16
+    for (int p = p0; p < p1; ++p) s2_pair_mask(a_masks, b_masks, pairs_a[p], pairs_b[p], bl, tid, cw);
+    int nnz_t = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) nnz_t += __popc(cw[q]);
+    // block-local exclusive prefixes of (tiles, entries)
+    const unsigned long long vb = __ballot(valid);
+    const int tile_rank_w = __popcll(vb & ((1ull << lane) - 1ull));
+    int inc = nnz_t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) {
+        w_tiles[wave] = __popcll(vb);
+        w_nnz[wave] = inc;
+    }
+    __syncthreads();
+    int tile_off = tile_rank_w, nnz_off = inc - nnz_t, blk_tiles = 0, blk_nnz = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) {
+            tile_off += w_tiles[w];
+            nnz_off += w_nnz[w];
+        }
+        blk_tiles += w_tiles[w];
+        blk_nnz += w_nnz[w];
+    }
+    // decoupled look-back: exclusive prefix of this block over all earlier tickets
+    if (wave == 0) {
+        const unsigned long long agg = (unsigned long long)blk_tiles | ((unsigned long long)blk_nnz << 31);
+        unsigned long long excl = 0;
+        if (blk == 0) {
+            if (lane == 0) __hip_atomic_store(&lb_state[0], (agg << 2) | LB_PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&lb_state[blk], (agg << 2) | LB_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int look = blk - 1, polls = 0;
+            while (true) {
+                const int idx = look - lane;
+                const unsigned long long v = idx >= 0 ? __hip_atomic_load(&lb_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_PREFIX;
+                const unsigned st = (unsigned)(v & 3ull);
+                const unsigned long long inv = __ballot(st == 0), pre = __ballot(st == 2);
+                const unsigned long long usable = inv ? ((inv & (~inv + 1ull)) - 1ull) : ~0ull;   // lanes nearer than the first unpublished block
+                const unsigned long long hit = pre & usable;
+                if (hit || !inv) {
+                    const int last = hit ? __builtin_ctzll(hit) : 63;                            // nearest block holding an inclusive prefix
+                    unsigned long long c = lane <= last ? (v >> 2) : 0ull;
+#pragma unroll
+                    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+                    excl += c;
+                    if (hit) break;
+                    look -= 64;
+                    continue;
+                }
+                if (++polls > LB_POLL_BUDGET) {   // cannot happen (see the header); never hang the device on a protocol bug
+                    if (lane == 0) flags[FLAG_CAPACITY] = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (lane == 0) __hip_atomic_store(&lb_state[blk], ((excl + agg) << 2) | LB_PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_excl = excl;
+    }
+    __syncthreads();
+    const unsigned long long excl = s_excl;
+    const long long tile_base = (long long)(excl & 0x7FFFFFFFull), nnz_base = (long long)(excl >> 31);
+    const long long t = tile_base + tile_off, off = nnz_base + nnz_off;
+    if (tid == 255) {   // inclusive prefix of the block (lane 255 holds the last offsets)
+        const long long tiles_incl = tile_base + blk_tiles, nnz_incl = nnz_base + blk_nnz;
+        if (nnz_incl > 0x7FFFFFFFll) flags[FLAG_OVERFLOW] = 1;
+        if (tiles_incl > cap_tiles || (WRITE_RC && nnz_incl > cap_nnz)) flags[FLAG_CAPACITY] = 1;
+        if ((long long)(blk + 1) * 256 >= nslots) {   // the block holding the last slot: totals and the closing offsets
+            d_scalars[1] = tiles_incl;
+            d_scalars[2] = nnz_incl;
+            if (tiles_incl <= cap_tiles) {
+                pairs_offset[tiles_incl] = (int)nslots;
+                c_tile_nnz_ptr[tiles_incl] = (int)nnz_incl;
+            }
+        }
+    }
+    if (!valid || t >= cap_tiles) return;
+    c_colidx[t] = col;
+    pairs_offset[t] = p0;
+    c_tile_nnz_ptr[t] = (int)off;
+    // reference packing: word q = (row 2q) << 16 | row 2q+1  (spgemm.cu:533-543)
+    *reinterpret_cast<uint4 *>(c_mask + 8 * t) = make_uint4((cw[0] << 16) | (cw[0] >> 16), (cw[1] << 16) | (cw[1] >> 16),
+                                                            (cw[2] << 16) | (cw[2] >> 16), (cw[3] << 16) | (cw[3] >> 16));
+    *reinterpret_cast<uint4 *>(c_mask + 8 * t + 4) = make_uint4((cw[4] << 16) | (cw[4] >> 16), (cw[5] << 16) | (cw[5] >> 16),
+                                                                (cw[6] << 16) | (cw[6] >> 16), (cw[7] << 16) | (cw[7] >> 16));
+    if constexpr (WRITE_RC) {
+        if (off + nnz_t <= cap_nnz) {
+            // step 3 deals C entries in chunks of S3_CHUNK: note the tile every chunk starts in (saves its waves a search)
+            for (long long ch = (off + S3_CHUNK - 1) / S3_CHUNK; ch * S3_CHUNK < off + nnz_t; ++ch) chunk_tile[ch] = (int)t;
+            s2_emit_rowcol(cw, c_rowcolidx + off);
+        }
+    }
 }
 
 // Ctiles_rowPtr (spgemm.cu:579-580) from the stored masks, one C tile per lane.  Nothing on the default path reads
@@ -988,8 +1147,8 @@ __global__ void __launch_bounds__(256) s2_crowptr_kernel(const uint32_t *__restr
     *reinterpret_cast<uint4 *>(c_rowptr + 16 * t) = make_uint4(rp[0], rp[1], rp[2], rp[3]);
 }
 
-constexpr int S3_CHUNK = 256;   // = S3_EPW below: C entries one wave of step 3 takes
-// a12 (spgemm.cu:582-587): packed (r<<4|c) bytes, one C tile per lane
+// a12 (spgemm.cu:582-587): packed (r<<4|c) bytes, one C tile per lane (first pass on a plan: the entry total is
+// only known once the fused kernel above has run, so the bytes follow in a launch of their own)
 __global__ void __launch_bounds__(256) s2_crowcol_wide_kernel(const uint32_t *__restrict__ c_mask, const int *__restrict__ c_tile_nnz_ptr,
                                                               long long ntc, uint8_t *__restrict__ c_rowcolidx, int *__restrict__ chunk_tile)
 {
@@ -1336,6 +1495,15 @@ extern "C" pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const p
     p->tr_hi = tr_hi;
     p->a_lo = A->h_tile_rowptr[(size_t)tr_lo];
     p->a_hi = A->h_tile_rowptr[(size_t)tr_hi];
+    // Options that change the SIZES of a pass are read once, here: a warm pass re-uses the sizes of the previous one,
+    // so they must not change under a plan.  PEM_S1_FORCE_KEY64 / PEM_S1_XLCAP are test hooks: they push small inputs
+    // through the code a B with more than 2^17 tile columns / a tile row beyond the LDS bins selects.
+    const char *e = getenv("PEM_PRUNE");
+    p->opt_prune = !(e && !strcmp(e, "0"));
+    e = getenv("PEM_S1_FORCE_KEY64");
+    p->opt_key64 = e && !strcmp(e, "1");
+    e = getenv("PEM_S1_XLCAP");
+    p->opt_xlcap = e ? atoi(e) : 0;
     *out = p;
     return PEM_OK;
 }
@@ -1386,8 +1554,7 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
     PEM_TRY(p->c_tile_rowptr.reserve(sizeof(int) * ((size_t)mt + 4)));
     PEM_HIP(hipMemsetAsync(p->c_tile_rowptr.p, 0, sizeof(int) * ((size_t)mt + 1), st));
     // product offsets per A tile: all products (expansion / sort capacity) and live products (output positions)
-    const char *prune_env = getenv("PEM_PRUNE");
-    const int prune = !(prune_env && !strcmp(prune_env, "0"));
+    const int prune = p->opt_prune;
     PEM_TRY(p->aprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
     PEM_TRY(p->lprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
     if (nA > 0)
@@ -1436,6 +1603,7 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_LAUNCH(ctx, s1_emit_ctiles_kernel, grid_for(n, 256), 256, keys, head.as<int>(), n, p->tr_lo, bits_tc, p->c_tile_rowidx.as<int>(),
                    p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>());
         p->c_rowidx_valid = true;
+        p->compact_valid = true;
         PEM_LAUNCH(ctx, s1_c_rowptr_kernel, grid_for(ntc, 256), 256, p->c_tile_rowidx.as<int>(), (long long)TC, p->tr_lo, mt,
                    p->c_tile_rowptr.as<int>());
     } else {
@@ -1521,12 +1689,16 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     const int bits_tc = bits_for((uint64_t)B->tile_cols), bits_row = bits_for((uint64_t)(mt > 0 ? mt : 1));
     // the 32768-key LDS bin needs 32-bit keys (tile col + 15 index bits); wider B goes to the global path above 8192
     // 32-bit keys = tile col + 15 index bits; wider B uses 64-bit keys (24 index bits, no 32768-key LDS bin)
-    const bool k32 = bits_tc + 15 <= 32;
+    // (a row of exactly 2^15 products in a B of exactly 2^17 tile columns could form the key 0xFFFFFFFF, which is the
+    // padding key: the index field holds 2^15 - 1 products at most)
+    const bool k32 = bits_tc + 15 <= 32 && !p->opt_key64;
     const int cap3 = k32 ? S1_CAP3 : S1_CAP2;
-    const int qcap = k32 ? (1 << 15) : (1 << 24);
+    const int qcap = k32 ? (1 << 15) - 1 : (1 << 24) - 1;
+    const int xlcap = p->opt_xlcap > 0 ? p->opt_xlcap : 0x7FFFFFFF;   // test hook: rows with more live products take the global path
     p->state = 0;
     p->pairs_ready = false;
     p->c_rowidx_valid = false;
+    p->compact_valid = false;
     p->ntiles_c = p->npairs = p->nnz_c = 0;
     if (!ctx->capturing) PEM_HIP(hipEventRecord(ctx->ev[0], st));
     PEM_TRY(p->c_tile_rowptr.reserve(sizeof(int) * ((size_t)mt + 4)));
@@ -1539,8 +1711,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     PEM_LAUNCH(ctx, s1_reset_kernel, 1, 64, ctx->d_flags, p->bin_count.as<int>(), reinterpret_cast<long long *>(ctx->d_scalars),
                p->pairs_offset.as<int>(), p->c_tile_rowptr.as<int>(), mt);
     // product offsets per A tile: all products (expansion / sort capacity) and live products (output positions)
-    const char *prune_env = getenv("PEM_PRUNE");
-    const int prune = !(prune_env && !strcmp(prune_env, "0"));
+    const int prune = p->opt_prune;
     PEM_TRY(p->aprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
     PEM_TRY(p->lprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
     if (nA > 0)
@@ -1550,7 +1721,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     // per-row tile counts are accumulated in c_tile_rowptr and scanned in place afterwards
     if (mt > 0)
         PEM_LAUNCH(ctx, s1_rowclass_kernel, grid_for((size_t)mt, 256), 256, A->tile_rowptr.as<int>(), p->tr_lo, mt, p->a_lo,
-                   p->aprod_off.as<int>(), p->lprod_off.as<int>(), cap3, qcap, p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(),
+                   p->aprod_off.as<int>(), p->lprod_off.as<int>(), cap3, qcap, xlcap, p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(),
                    p->c_tile_rowptr.as<int>());
     // one read-back: P, the bin populations and the product total of the oversized rows
     int64_t P = 0, Pall = 0;
@@ -1625,17 +1796,33 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
             PEM_TRY(read_scalars(ctx, ctx->d_scalars + 1, 1, &TC));
             p->w_TC = TC;
         }
-        const size_t ntc = (size_t)TC;
-        PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
-        PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
-        PEM_LAUNCH(ctx, s1_compact_kernel, (unsigned)mt, 256, p->c_tile_rowptr.as<int>(), mt, (long long)TC, p->tr_lo,
-                   A->tile_rowptr.as<int>(), p->a_lo, p->lprod_off.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), (int)P,
-                   p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>());
+        // _C_tileColIdx and the pair offsets in the reference's dense layout are written by step 2's fused kernel
+        // straight from the row-local scratch; a caller that stops after step 1 gets them from ensure_compact()
         p->pairs_ready = true;
     }
     p->ntiles_c = TC;
     if (!ctx->capturing) PEM_HIP(hipEventRecord(ctx->ev[1], st));
     p->state = 1;
+    return PEM_OK;
+}
+
+// row-local scratch -> _C_tileColIdx / pair offsets (reference layout) without step 2: the step-wise API after step 1,
+// and the 16-lanes-per-tile baseline kernels
+static pem_status ensure_compact(pem_ctx *ctx, const pem_cplan *cp)
+{
+    pem_cplan *p = const_cast<pem_cplan *>(cp);
+    if (p->compact_valid || !p->pairs_ready || p->state < 1) return PEM_OK;
+    const pem_tiled *A = p->A;
+    const int mt = p->tr_hi - p->tr_lo;
+    const size_t ntc = (size_t)p->ntiles_c;
+    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
+    PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
+    if (mt > 0)
+        PEM_LAUNCH(ctx, s1_compact_kernel, (unsigned)mt, 256, p->c_tile_rowptr.as<int>(), mt, (long long)ntc, p->tr_lo, A->tile_rowptr.as<int>(),
+                   p->a_lo, p->lprod_off.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), (int)p->npairs,
+                   p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>());
+    p->compact_valid = true;
     return PEM_OK;
 }
 
@@ -1667,45 +1854,89 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
     PEM_TRY(p->c_mask.reserve(sizeof(uint32_t) * 8 * (ntc + 1)));
     PEM_TRY(p->c_tile_nnz_ptr.reserve(sizeof(int) * (ntc + 4)));
     p->c_rowptr_valid = false;
-    if (n > 0 && !p->pairs_ready)
-        PEM_LAUNCH(ctx, s2_pairs_kernel, grid_for(n, 256), 256, p->sorted_perm, p->prod_a.as<int>(), p->prod_b.as<int>(), n, p->pairs_a.as<int>(),
-                   p->pairs_b.as<int>());
     const char *wide_env = getenv("PEM_WIDE");
-    const bool wide = !(wide_env && !strcmp(wide_env, "0"));
-    if (ntc > 0) {
-        if (wide)
-            PEM_LAUNCH(ctx, s2_cmask_wide_kernel, grid_for(ntc, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
-                       (long long)ntc, A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>());
-        else
+    // the fused kernel reads the row-local scratch of the default step 1; the global-sort step 1 (PEM_STEP1=esc) and
+    // PEM_WIDE=0 take the 16-lanes-per-tile baseline kernels over the dense layout
+    const bool fused = p->pairs_ready && !(wide_env && !strcmp(wide_env, "0"));
+    p->wide = fused;
+    int64_t nnzc = 0;
+    if (fused) {
+        PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
+        PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
+        if (n > 0) {
+            const size_t nblk = (n + 255) / 256;
+            PEM_TRY(p->lb_state.reserve(sizeof(unsigned long long) * (nblk + 2)));
+            PEM_HIP(hipMemsetAsync(p->lb_state.p, 0, sizeof(unsigned long long) * (nblk + 2), st));
+            unsigned long long *lb = p->lb_state.as<unsigned long long>();
+            int *ticket = reinterpret_cast<int *>(lb + nblk);
+            if (p->warm_pass) {   // sizes known: the (r<<4|c) bytes and step 3's chunk index come out of the same launch
+                nnzc = p->w_nnz;
+                PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
+                PEM_TRY(p->s3_chunk_tile.reserve(sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)));
+                PEM_LAUNCH_NAMED(ctx, "s2_tiles_kernel<rc>", s2_tiles_kernel<true>, (unsigned)nblk, 256, p->scratch_col.as<int>(), p->scratch_off.as<int>(),
+                                 (long long)n, p->pairs_a.as<int>(), p->pairs_b.as<int>(), A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), lb, ticket,
+                                 (long long)ntc, (long long)nnzc, p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>(), p->c_mask.as<uint32_t>(),
+                                 p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->s3_chunk_tile.as<int>(),
+                                 reinterpret_cast<long long *>(ctx->d_scalars), ctx->d_flags);
+            } else {
+                PEM_LAUNCH_NAMED(ctx, "s2_tiles_kernel", s2_tiles_kernel<false>, (unsigned)nblk, 256, p->scratch_col.as<int>(), p->scratch_off.as<int>(),
+                                 (long long)n, p->pairs_a.as<int>(), p->pairs_b.as<int>(), A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), lb, ticket,
+                                 (long long)ntc, 0ll, p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>(), p->c_mask.as<uint32_t>(),
+                                 p->c_tile_nnz_ptr.as<int>(), (uint8_t *)nullptr, (int *)nullptr, reinterpret_cast<long long *>(ctx->d_scalars),
+                                 ctx->d_flags);
+                int64_t sc[2];
+                PEM_TRY(read_scalars(ctx, ctx->d_scalars + 1, 2, sc));
+                if (sc[0] != (int64_t)ntc) {
+                    set_error("step 2: %lld C tiles found, step 1 counted %zu", (long long)sc[0], ntc);
+                    return PEM_E_STATE;
+                }
+                nnzc = sc[1];
+            }
+            p->compact_valid = true;
+        } else {
+            PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_nnz_ptr.as<int>(), p->c_tile_nnz_ptr.as<int>(), 0, ctx->d_scalars + 2));
+            p->compact_valid = true;   // pairs_offset[0] = 0 was set by step 1's reset
+        }
+    } else {
+        PEM_TRY(ensure_compact(ctx, p));
+        if (n > 0 && !p->pairs_ready)
+            PEM_LAUNCH(ctx, s2_pairs_kernel, grid_for(n, 256), 256, p->sorted_perm, p->prod_a.as<int>(), p->prod_b.as<int>(), n, p->pairs_a.as<int>(),
+                       p->pairs_b.as<int>());
+        if (ntc > 0)
             PEM_LAUNCH(ctx, s2_cmask_kernel, grid_for(ntc * 16, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
                        (long long)ntc, A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>());
+        PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_nnz_ptr.as<int>(), p->c_tile_nnz_ptr.as<int>(), ntc, ctx->d_scalars + 2));
+        if (p->warm_pass) {
+            nnzc = p->w_nnz;
+        } else {
+            PEM_TRY(read_scalars(ctx, ctx->d_scalars + 2, 1, &nnzc));
+        }
     }
-    PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_nnz_ptr.as<int>(), p->c_tile_nnz_ptr.as<int>(), ntc, ctx->d_scalars + 2));
-    int64_t nnzc = 0;
-    if (p->warm_pass) {
-        nnzc = p->w_nnz;
-    } else {
-        PEM_TRY(read_scalars(ctx, ctx->d_scalars + 2, 1, &nnzc));
+    if (!p->warm_pass) {
+        int hf[NUM_FLAGS];
+        PEM_TRY(read_flags(ctx, hf));
+        if (hf[FLAG_OVERFLOW] || nnzc > 0x7FFFFFFFll) {
+            set_error("step 2: C has more than 2^31-1 nonzeros, beyond the int32 range of the reference's offsets");
+            return PEM_E_OVERFLOW;
+        }
+        if (hf[FLAG_CAPACITY]) {
+            set_error("step 2: the C tile scan did not complete");
+            return PEM_E_STATE;
+        }
         p->w_nnz = nnzc;
-    }
-    if (nnzc > 0x7FFFFFFFll) {
-        set_error("step 2: C has %lld nonzeros, beyond the int32 range of the reference's offsets", (long long)nnzc);
-        return PEM_E_OVERFLOW;
     }
     p->nnz_c = nnzc;
     PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
     PEM_TRY(p->s3_chunk_tile.reserve(sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)));
     PEM_TRY(p->c_vals.reserve((size_t)A->value_bytes * ((size_t)nnzc + 1)));
-    if (ntc > 0) {
-        if (wide)
-            PEM_LAUNCH(ctx, s2_crowcol_wide_kernel, grid_for(ntc, 256), 256, p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
-                       p->c_rowcolidx.as<uint8_t>(), p->s3_chunk_tile.as<int>());
-        else {   // the 16-lanes-per-tile baseline writes Ctiles_rowPtr as it goes, like the reference (spgemm.cu:579-580)
-            PEM_TRY(p->c_rowptr.reserve(16 * (ntc + 1)));
-            PEM_LAUNCH(ctx, s2_crowcol_kernel, grid_for(ntc * 16, 256), 256, p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
-                       p->c_rowptr.as<uint8_t>(), p->c_rowcolidx.as<uint8_t>());
-            p->c_rowptr_valid = true;
-        }
+    if (ntc > 0 && fused && !p->warm_pass)
+        PEM_LAUNCH(ctx, s2_crowcol_wide_kernel, grid_for(ntc, 256), 256, p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
+                   p->c_rowcolidx.as<uint8_t>(), p->s3_chunk_tile.as<int>());
+    if (ntc > 0 && !fused) {   // the 16-lanes-per-tile baseline writes Ctiles_rowPtr as it goes, like the reference (spgemm.cu:579-580)
+        PEM_TRY(p->c_rowptr.reserve(16 * (ntc + 1)));
+        PEM_LAUNCH(ctx, s2_crowcol_kernel, grid_for(ntc * 16, 256), 256, p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
+                   p->c_rowptr.as<uint8_t>(), p->c_rowcolidx.as<uint8_t>());
+        p->c_rowptr_valid = true;
     }
     if (!ctx->capturing) PEM_HIP(hipEventRecord(ctx->ev[3], st));
     p->state = 2;
@@ -1722,8 +1953,7 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
     hipStream_t st = ctx->stream;
     const size_t ntc = (size_t)p->ntiles_c;
     if (!ctx->chain_events) PEM_HIP(hipEventRecord(ctx->ev[4], st));
-    const char *wide_env = getenv("PEM_WIDE");
-    const bool wide = !(wide_env && !strcmp(wide_env, "0"));
+    const bool wide = p->wide;   // step 2's choice: the entry-per-lane kernel needs the chunk index the fused path wrote
     const bool f32 = A->value_bytes == 4;
 #define PEM_S3_LAUNCH(VT)                                                                                                                      \
     do {                                                                                                                                       \
@@ -1754,6 +1984,7 @@ extern "C" pem_status pem_spgemm_step1(pem_ctx *ctx, pem_cplan *plan)
     if (!ctx || !plan) return PEM_E_INVALID;
     PEM_HIP(hipSetDevice(ctx->device));
     PEM_TRY(step1_impl(ctx, plan, false));   // step-wise calls always read the sizes back
+    PEM_TRY(ensure_compact(ctx, plan));      // ... and leave step 1's outputs in the reference layout
     PEM_HIP(hipStreamSynchronize(ctx->stream));
     return step_elapsed(ctx, 0, 1, &ctx->timings.step1_ms);
 }
@@ -1919,8 +2150,16 @@ extern "C" pem_status pem_cplan_get_array(pem_ctx *ctx, const pem_cplan *p, pem_
         src = p->c_tile_rowidx.p;
         want = 4 * TC;
         break;
-    case PEM_C_TILE_COLIDX: src = p->c_tile_colidx.p; want = 4 * TC; break;
-    case PEM_C_PAIRS_OFFSET: src = p->pairs_offset.p; want = 4 * (TC + 1); break;
+    case PEM_C_TILE_COLIDX:
+        PEM_TRY(ensure_compact(ctx, p));
+        src = p->c_tile_colidx.p;
+        want = 4 * TC;
+        break;
+    case PEM_C_PAIRS_OFFSET:
+        PEM_TRY(ensure_compact(ctx, p));
+        src = p->pairs_offset.p;
+        want = 4 * (TC + 1);
+        break;
     case PEM_C_PAIRS_A: src = p->pairs_a.p; want = 4 * P; need = 2; break;
     case PEM_C_PAIRS_B: src = p->pairs_b.p; want = 4 * P; need = 2; break;
     case PEM_C_MASK: src = p->c_mask.p; want = 32 * TC; need = 2; break;

@@ -62,8 +62,8 @@ def cases():
     out["diag_100"] = (100, 100, np.arange(100, dtype=np.int32), np.arange(100, dtype=np.int32), _vals(rng, 100), False)
     # wide: more than 16384 tile columns (the reference's step-1 dispatch boundary, spgemm.cu:1142)
     out["wide_tilecols"] = random_coo(rng, 16385 * 16, 64, 900) + (True,)
-    # tile rows with many products: 40 tiles x 40 tiles (1600 products/row: 1024-thread LDS bin) and
-    # 100 x 100 (10000 products/row: beyond the LDS bins -> global radix-sort path), plus one hub row
+    # tile rows with many products: 40 tiles x 40 tiles (1600 products/row: the four-wave LDS bin) and
+    # 100 x 100 (10000 products/row: the 32768-key LDS bin; the global path with 64-bit keys), plus one hub row
     for nm, ntc in (("blockrows_1600", 40), ("blockrows_10000", 100)):
         n = 16 * ntc
         I = np.repeat(np.arange(n), ntc)
@@ -75,4 +75,48 @@ def cases():
     J = np.concatenate([np.arange(n), np.arange(n), rng.integers(0, n, 6000)])
     key = rng.permutation(np.unique(I.astype(np.int64) * n + J))
     out["hub_row_4000"] = (n, n, (key // n).astype(np.int32), (key % n).astype(np.int32), _vals(rng, len(key)), False)
+    out.update(step1_cases(rng))
+    return out
+
+
+def _grouped(rng, rows, ngroups, counts, hubs):
+    """A (rows x 16*ngroups): `counts[k]` single entries in tile column k at distinct random rows, mostly in column
+    16k+5 (so that products between tiles of one group are live) and a few elsewhere (so that pruning has work);
+    hubs: list of (row, groups) -- rows holding an entry in each of the listed groups."""
+    I, J = [], []
+    for k, cnt in enumerate(counts):
+        r = rng.choice(rows, size=cnt, replace=False)
+        c = np.where(rng.random(cnt) < 0.85, 16 * k + 5, 16 * k + rng.integers(0, 16, cnt))
+        I.append(r)
+        J.append(c)
+    for r, groups in hubs:
+        I.append(np.full(len(groups), r))
+        J.append(np.array([16 * k + 5 for k in groups]))
+    I, J = np.concatenate(I).astype(np.int64), np.concatenate(J).astype(np.int64)
+    key = rng.permutation(np.unique(I * (16 * ngroups) + J))
+    return rows, 16 * ngroups, (key // (16 * ngroups)).astype(np.int32), (key % (16 * ngroups)).astype(np.int32), _vals(rng, len(key)), True
+
+
+def step1_cases(rng):
+    """The step-1 code a cage15-class input selects (VERDICT r1 #1), reached WITHOUT test hooks."""
+    out = {}
+    # (i) B = A^T with 131 250 > 2^17 tile columns: keys need 64 bits.  A tile row of A*A^T with one entry in group k
+    # has counts[k] products (bins <=512 and <=2048); hub rows with entries in many groups reach the <=8192 bin
+    # (7 955 products) and go beyond it (9 855: above the largest LDS bin with 64-bit keys), so the global expand /
+    # radix sort / emit path runs next to the LDS bins.
+    counts = [215] * 37 + [100, 700, 1100]
+    out["k64_bins"] = _grouped(rng, 2_100_000, 40, counts,
+                               [(777_777, list(range(40))), (1_234_567, list(range(37))), (42, [0, 1, 2, 3, 38]), (2_099_999, [37, 39])])
+    # (ii) 32-bit keys, tile rows above 32 768 live products next to rows of every LDS bin: A is 400 x 210 tiles,
+    # tile rows 0..159 hold all 210 tiles (so every tile column of A = tile row of A^T has >= 160 tiles and a full
+    # row has >= 33 600 products), the others hold 1..100 tiles.
+    I, J = [], []
+    for i in range(400):
+        nt = 210 if i < 160 else (1, 2, 3, 10, 40, 100)[i % 6]
+        ks = np.arange(210) if nt == 210 else rng.choice(210, size=nt, replace=False)
+        I.append(np.full(nt, 16 * i + (i * 5) % 16))
+        J.append(16 * ks + np.where(rng.random(nt) < 0.9, 5, rng.integers(0, 16, nt)))
+    I, J = np.concatenate(I), np.concatenate(J)
+    p = rng.permutation(len(I))
+    out["xl_mixed_AAt"] = (6400, 3360, I[p].astype(np.int32), J[p].astype(np.int32), _vals(rng, len(I)), True)
     return out

@@ -141,6 +141,31 @@ def test_full_size_against_cpu_port(pkg, oracle, standins, ctx, name, scale):
     assert np.array_equal(rp2, rp) and np.array_equal(ci2, ci) and np.array_equal(v2, v)
 
 
+def test_cage15_rank_slice_against_cpu_port(pkg, oracle, standins, ctx):
+    """BASELINE configs[4]: rank 0's share of the 8-way row-block split of the FULL-SIZE cage15 stand-in (5 154 859^2,
+    99 199 551 nnz).  B has 322 179 tile columns, so step 1 runs its 64-bit-key row sorts, and B is far larger than
+    the caches.  The exported CSR of the slice must equal the OpenMP Gustavson port on the same rows bit for bit."""
+    rows, cols, I, J, V = standins.make("cage15", 1.0)
+    A = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V)
+    assert A.tile_cols > (1 << 17)
+    bounds = pkg.split_tile_rows(ctx, A, A, 8)
+    lo, hi = int(bounds[0]), int(bounds[1])
+    plan = pkg.CPlan(ctx, A, A, lo, hi)
+    plan.spgemm()
+    plan.spgemm()                                                  # warm pass: same result
+    rp, ci, v = plan.export_csr()
+    info = plan.info()
+    assert info["row_begin"] == 16 * lo and info["nnz_c"] == len(ci)
+    r0, r1 = info["row_begin"], info["row_end"]
+    sel = (I >= r0) & (I < r1)
+    oa = oracle.Csr(r1 - r0, cols, I[sel] - r0, J[sel], V[sel])     # the slice's rows of A ...
+    ob = oracle.Csr(rows, cols, I, J, V)                            # ... times all of B
+    del I, J, V, sel
+    rp0, ci0, v0 = oracle.csr_spgemm(oa, ob, oracle.max_threads()).arrays()
+    assert np.array_equal(rp, rp0) and np.array_equal(ci, ci0)
+    assert np.array_equal(v, v0)
+
+
 def test_cli_distinct_b_and_mtx_output(pkg, oracle, standins, tmp_path):
     """C = A*B with two files and a Matrix-Market result (beyond the reference's A^2 / A*A^T)."""
     import scipy.io

@@ -14,13 +14,29 @@ C_NAMES = ["c_tile_rowptr", "c_tile_rowidx", "c_tile_colidx", "pairs_offset", "p
            "c_rowptr", "c_rowcolidx", "c_vals"]
 
 
+_ORACLE_TILED = {}     # the big step-1 cases take the oracle ~15 s to tile: once per session is enough
+
+
 def _tiled_pair(pkg, oracle, ctx, case):
     rows, cols, I, J, V, tr = case
     gA = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V, False)
     gB = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V, True) if tr else gA
-    oA = oracle.Tiled(rows, cols, I, J, V, False)
-    oB = oracle.Tiled(rows, cols, I, J, V, True) if tr else oA
+    key = (rows, cols, len(I), int(I.sum()) if len(I) else 0, tr)
+    if key not in _ORACLE_TILED:
+        oA = oracle.Tiled(rows, cols, I, J, V, False)
+        _ORACLE_TILED[key] = (oA, oracle.Tiled(rows, cols, I, J, V, True) if tr else oA)
+    oA, oB = _ORACLE_TILED[key]
     return gA, gB, oA, oB
+
+
+_ORACLE_PLAN = {}
+
+
+def _oracle_plan(oracle, oA, oB):
+    key = (id(oA), id(oB))
+    if key not in _ORACLE_PLAN:
+        _ORACLE_PLAN[key] = oracle.Plan(oA, oB)
+    return _ORACLE_PLAN[key]
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -40,7 +56,7 @@ def test_three_steps_match_oracle(pkg, oracle, ctx, name):
     plan.step1()
     plan.step2()
     plan.step3()
-    op = oracle.Plan(oA, oB)
+    op = _oracle_plan(oracle, oA, oB)
     info = plan.info()
     want_arrays, want_counts = expected(op, oA, oB)      # the oracle's arrays minus dead pairs / empty tiles
     assert (info["ntiles_c"], info["npairs"], info["nnz_c"], info["npairs_all"]) == want_counts
@@ -142,7 +158,7 @@ def test_unpruned_lists_are_the_reference_lists(pkg, oracle, ctx, name, monkeypa
     reference-faithful oracle's exactly -- for the row-local and for the global step 1."""
     monkeypatch.setenv("PEM_PRUNE", "0")
     gA, gB, oA, oB = _tiled_pair(pkg, oracle, ctx, CASES[name])
-    op = oracle.Plan(oA, oB)
+    op = _oracle_plan(oracle, oA, oB)
     for mode in ("rows", "esc"):
         monkeypatch.setenv("PEM_STEP1", mode)
         plan = pkg.CPlan(ctx, gA, gB)
@@ -151,3 +167,51 @@ def test_unpruned_lists_are_the_reference_lists(pkg, oracle, ctx, name, monkeypa
         assert (info["ntiles_c"], info["npairs"], info["nnz_c"], info["npairs_all"]) == (op.ntiles_c, op.npairs, op.nnz_c, op.npairs)
         for arr in C_NAMES:
             assert np.array_equal(plan.array(arr), getattr(op, arr)), f"{name}/{mode}: plan array {arr} differs (unpruned)"
+
+
+HOOKS = {"key64": {"PEM_S1_FORCE_KEY64": "1"}, "xl300": {"PEM_S1_XLCAP": "300"},
+         "key64+xl300": {"PEM_S1_FORCE_KEY64": "1", "PEM_S1_XLCAP": "300"}, "xl40": {"PEM_S1_XLCAP": "40"}}
+
+
+@pytest.mark.parametrize("prune", ["1", "0"])
+@pytest.mark.parametrize("hook", list(HOOKS))
+@pytest.mark.parametrize("name", ["powerlaw_600", "hub_row_4000", "blockrows_1600", "blockrows_10000", "dense_48", "rect_70x40_AAt",
+                                  "wide_tilecols", "xl_mixed_AAt"])
+def test_step1_wide_key_and_oversized_row_paths(pkg, oracle, ctx, name, hook, prune, monkeypatch):
+    """The step-1 code a cage15-class input selects, forced onto small inputs: PEM_S1_FORCE_KEY64=1 runs the uint64-key
+    row sorts (taken when B has more than 2^17 tile columns; with them the largest LDS bin is 8192 keys, so
+    blockrows_10000 also takes the 64-bit global path), PEM_S1_XLCAP=n sends every tile row above n live products
+    through s1_xl_expand -> radix sort -> s1_xl_rowstart -> s1_xl_emit next to rows that stay in the LDS bins.  All
+    step-1/2/3 arrays against the oracle, pruned and unpruned (= the reference's own lists)."""
+    for k, v in HOOKS[hook].items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("PEM_PRUNE", prune)
+    gA, gB, oA, oB = _tiled_pair(pkg, oracle, ctx, CASES[name])
+    op = _oracle_plan(oracle, oA, oB)
+    want_arrays, want_counts = expected(op, oA, oB, prune == "1")
+    plan = pkg.CPlan(ctx, gA, gB)
+    for rnd in range(2):                      # cold pass, then a warm one (sizes re-used, no read-backs)
+        plan.spgemm()
+        info = plan.info()
+        assert (info["ntiles_c"], info["npairs"], info["nnz_c"], info["npairs_all"]) == want_counts
+        for arr in C_NAMES:
+            assert np.array_equal(plan.array(arr), want_arrays[arr]), f"{name}/{hook}/prune={prune}/pass {rnd}: {arr} differs"
+
+
+def test_options_are_latched_at_plan_creation(pkg, oracle, ctx, monkeypatch):
+    """PEM_PRUNE changes the sizes of a pass; a warm plan re-uses sizes, so the option is read once, when the plan is
+    made: flipping the environment under a live plan must not change (or corrupt) what it computes."""
+    gA, gB, oA, oB = _tiled_pair(pkg, oracle, ctx, CASES["powerlaw_600"])
+    op = _oracle_plan(oracle, oA, oB)
+    plan = pkg.CPlan(ctx, gA, gB)
+    plan.spgemm()
+    plan.spgemm()
+    monkeypatch.setenv("PEM_PRUNE", "0")
+    plan.spgemm()                                         # still the pruned lists
+    want_arrays, want_counts = expected(op, oA, oB, True)
+    assert plan.info()["npairs"] == want_counts[1]
+    for arr in C_NAMES:
+        assert np.array_equal(plan.array(arr), want_arrays[arr]), arr
+    plan2 = pkg.CPlan(ctx, gA, gB)                        # a new plan sees the new value
+    plan2.spgemm()
+    assert plan2.info()["npairs"] == op.npairs
