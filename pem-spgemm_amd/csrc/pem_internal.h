@@ -217,7 +217,8 @@ struct pem_cplan {
     bool pairs_ready = false;          // step 1 already wrote pairs_a / pairs_b
     bool wide = true;                  // step 2 ran the fused kernel (step 3 then runs entry-per-lane); false: 16-lanes-per-tile baseline
     bool compact_valid = false;        // c_tile_colidx / pairs_offset hold the dense layout (else: row-local scratch, see ensure_compact)
-    pem::DevBuf lb_state;              // step 2 look-back: one 64-bit word per 256-slot block + the ticket counter behind them
+    pem::DevBuf block_info;            // int2 per 256-slot block of the step-1 scratch: (tile row of the block's first slot, its position in the row's range)
+    pem::DevBuf group_nnz;             // C entries per S2_GROUP tiles (s2_tiles_kernel -> scan -> s2_entries_kernel)
     // sizes of the last complete pass on this plan.  A and B are immutable, so a repeat pass has the same
     // sizes: it skips the three host read-backs and a device-side check compares them at the end instead.
     hipGraphExec_t graph_exec = nullptr;   // PEM_GRAPH=1: the captured warm pass

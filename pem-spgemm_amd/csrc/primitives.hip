@@ -226,7 +226,7 @@ __global__ void scan_empty_kernel(int *out, long long *total64)
 }
 
 // short arrays (row counts of a slice, histogram tails): one 1024-thread block does the whole scan in one launch
-constexpr size_t SCAN_SMALL = 65536;
+constexpr size_t SCAN_SMALL = 131072;
 __global__ void __launch_bounds__(1024) scan_small_kernel(const int *in, int *out, size_t n, long long *__restrict__ total64,
                                                           int *__restrict__ flags)
 {

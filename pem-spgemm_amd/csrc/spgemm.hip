@@ -572,7 +572,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
                                                              const uint32_t *__restrict__ a_occ, const uint32_t *__restrict__ b_occ, int prune,
                                                              int *__restrict__ pairs_a, int *__restrict__ pairs_b,
                                                              int *__restrict__ scratch_col, int *__restrict__ scratch_off,
-                                                             int *__restrict__ row_tc, int key_bits)
+                                                             int2 *__restrict__ block_info, int *__restrict__ row_tc, int key_bits)
 {
     constexpr int LOGT = THREADS == 64 ? 6 : THREADS == 256 ? 8 : 10;
     constexpr int EMAX = CAP / THREADS;
@@ -703,6 +703,9 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
             scratch_col[lp0 + x] = -1;
             scratch_off[lp0 + x] = lp0 + nlive;
         }
+        // step 2 walks the slots in blocks of 256: note, for every block boundary inside this row's range, the row and
+        // the boundary's position in the range (how many of the row's slots lie before it)
+        for (int b = (lp0 + 255) / 256 + tid; b * 256 < lp0 + nlive; b += THREADS) block_info[b] = make_int2(i, b * 256 - lp0);
         if (tid == 0) row_tc[i] = base;
         S1_DBG_MARK(3);
 #ifdef PEM_S1_DEBUG
@@ -736,7 +739,7 @@ __global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint3
                                   int bits_tc, const int *__restrict__ xl_rowstart, const int *__restrict__ a_tile_rowptr, int tr_lo, int a_lo,
                                   const int *__restrict__ aprod_off, const int *__restrict__ prod_a, const int *__restrict__ prod_b,
                                   int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ scratch_col,
-                                  int *__restrict__ scratch_off, int *__restrict__ row_tc)
+                                  int *__restrict__ scratch_off, int2 *__restrict__ block_info, int *__restrict__ row_tc)
 {
     size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n) return;
@@ -760,6 +763,7 @@ __global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint3
         scratch_col[p0 + s] = -1;
         scratch_off[p0 + s] = p0 + ni;
     }
+    if (((p0 + s) & 255) == 0) block_info[(p0 + s) >> 8] = make_int2(i, s);   // block boundary of step 2 (see s1_rowsort_kernel)
     if (s == 0) row_tc[i] = ntiles_row;
 }
 
@@ -977,44 +981,51 @@ __device__ __forceinline__ void s2_emit_rowcol(const unsigned (&cw)[8], uint8_t 
 constexpr int S3_CHUNK = 256;   // = S3_EPW below: C entries one wave of step 3 takes
 
 // ------------------------------------------------------------------------------------------
-// Step 2 in ONE kernel (a10 offsets + a11 + a12, spgemm.cu:483-484, 499-550, 552-591) over the row-local
+// Step 2 (a10 offsets + a11 + a12, spgemm.cu:483-484, 499-550, 552-591) in two kernels over the row-local
 // step-1 scratch.  Step 1 leaves, for every live product slot s in [0, P): scratch_col[s] = tile column of the
 // C tile whose pair list starts there (or -1: no tile starts in this slot), scratch_off[s] = first pair of
 // that tile (a gap slot holds the end of its row's pairs, so the end of any tile's pairs is scratch_off[s+1]).
 // A row's tiles sit at the front of the row's slot range in ascending column order, so the valid slots, read
-// in slot order, ARE the C tile list in the reference's order.  One slot per lane:
-//   mask      boolean product over the tile's pairs (two 16-byte loads per operand tile)
-//   position  the tile's index t and the offset of its entries are exclusive prefix sums over all earlier
-//             slots: block-local scan + decoupled look-back over the blocks' (tiles, entries) aggregates,
-//             packed into one 64-bit word per block so that one store publishes both consistently
-//   outputs   _C_tileColIdx[t], pairs offset[t], Ctiles_mask[8t..], perTileNnz offset[t], and -- when the
-//             entry total is known beforehand (repeat pass) -- the (r<<4|c) bytes and step 3's chunk index.
-// This replaces s1_compact + the C-tile scan + the mask kernel + the entry scan (3 launches) + the (r<<4|c)
-// kernel: the 32-byte masks are not re-read, the per-tile offsets are written once instead of written,
-// scanned and re-read.  Blocks take their slot range by a ticket, so a block only ever waits for blocks
-// that started before it (they are resident and never wait for a later one): the look-back cannot deadlock;
-// a poll budget turns any protocol failure into FLAG_CAPACITY instead of a hang.
+// in slot order, ARE the C tile list in the reference's order.
+//
+// s2_tiles_kernel, one slot per lane, 256 slots per block:
+//   index   the tile's index t = number of valid slots before it = (valid slots before the block) + ballot rank.
+//           Step 1 notes for every block boundary the tile row it falls in and how far into the row's slots
+//           (block_info); with _C_rowPtr that gives the first term in three scalar loads -- no scan over slots,
+//           no dependence between blocks.
+//   mask    boolean product over the tile's pairs (two 16-byte loads per operand tile)
+//   out     _C_tileColIdx[t], pair offsets[t], Ctiles_mask[8t..] straight into the reference's dense layout --
+//           this replaces s1_compact -- and the entry count of every 256 tiles (one integer atomic per wave and
+//           group) for the entry offsets.
+// (one small scan of the 256-tile group counts in between)
+// s2_entries_kernel, one tile per lane: perTileNnz offsets from the group base + a block scan of the masks'
+//   popcounts, the (r<<4|c) bytes, and step 3's chunk index -- replacing the 3-launch scan over all tiles.
+//
+// Measured and dropped: carrying (tiles, entries) through a decoupled look-back inside ONE kernel.  Flat window
+// of 64 blocks: 1.27 ms (2000 blocks in flight = 30 round trips of ~2 us agent-scope loads behind the nearest
+// prefix); with a ticket for the block order 1.40 ms (81 k atomics on one address, 11 ns each); two-level
+// (groups of 64 blocks): 1.20 ms -- in-order completion puts every resident block behind the slowest lane of the
+// oldest one, and a lane with a 40-pair tile takes 80 us; tile counts only, published at block start: 0.94 ms
+// with every block polling from its first cycle, 0.78 ms with the look-back moved behind the mask loop; without
+// any look-back the same kernel takes 0.36 ms.
 // ------------------------------------------------------------------------------------------
-constexpr unsigned long long LB_AGG = 1ull, LB_PREFIX = 2ull;   // status in bits 0-1; tiles in bits 2-32, entries in bits 33-63
-constexpr int LB_POLL_BUDGET = 1 << 22;
+constexpr int S2_GROUP = 256;             // tiles per block of s2_entries_kernel
 
-template <bool WRITE_RC>
 __global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ scratch_col, const int *__restrict__ scratch_off, long long nslots,
+                                                       const int2 *__restrict__ block_info, const int *__restrict__ c_rowptr,
                                                        const int *__restrict__ pairs_a, const int *__restrict__ pairs_b,
-                                                       const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks,
-                                                       unsigned long long *lb_state, int *lb_ticket, long long cap_tiles, long long cap_nnz,
+                                                       const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks, long long ntc,
                                                        int *__restrict__ c_colidx, int *__restrict__ pairs_offset, uint32_t *__restrict__ c_mask,
-                                                       int *__restrict__ c_tile_nnz_ptr, uint8_t *__restrict__ c_rowcolidx,
-                                                       int *__restrict__ chunk_tile, long long *__restrict__ d_scalars, int *__restrict__ flags)
+                                                       int *__restrict__ group_nnz)
 {
     __shared__ unsigned bl[8][256];
-    __shared__ int s_ticket;
-    __shared__ int w_tiles[4], w_nnz[4];
-    __shared__ unsigned long long s_excl;
+    __shared__ int w_tiles[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_ticket = atomicAdd(lb_ticket, 1);
-    __syncthreads();
-    const int blk = s_ticket;
+    const int blk = blockIdx.x;
+    // valid slots before this block: the tiles of all earlier tile rows + those of the boundary row that lie before it
+    const int2 bi = block_info[blk];                         // (tile row of slot 256 blk, that slot's position in the row's range)
+    const int row_t0 = c_rowptr[bi.x], row_tiles = c_rowptr[bi.x + 1] - row_t0;
+    const long long t_blk = (long long)row_t0 + (bi.y < row_tiles ? bi.y : row_tiles);
     const long long s = (long long)blk * 256 + tid;
     int col = -1, p0 = 0, p1 = 0;
     if (s < nslots) {
@@ -1025,104 +1036,93 @@ __global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ s
         }
     }
     const bool valid = col >= 0;
+    const unsigned long long vb = __ballot(valid);
+    if (lane == 0) w_tiles[wave] = __popcll(vb);
+    if (blk == 0 && tid == 0) pairs_offset[ntc] = (int)nslots;   // closing pair offset
+    __syncthreads();
+    int tile_off = __popcll(vb & ((1ull << lane) - 1ull));
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wave) tile_off += w_tiles[w];
+    const long long t = t_blk + tile_off;
+    // the masks
     unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // natural layout: cw[q] = row 2q | row 2q+1 << 16
     for (int p = p0; p < p1; ++p) s2_pair_mask(a_masks, b_masks, pairs_a[p], pairs_b[p], bl, tid, cw);
     int nnz_t = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) nnz_t += __popc(cw[q]);
-    // block-local exclusive prefixes of (tiles, entries)
-    const unsigned long long vb = __ballot(valid);
-    const int tile_rank_w = __popcll(vb & ((1ull << lane) - 1ull));
+    const bool store = valid && t < ntc;          // (t < ntc always: both count the same valid slots)
+    // entry counts per group of S2_GROUP tiles: a wave's tiles are consecutive, so they span at most two groups
+    {
+        const long long t_first = __shfl(t, vb ? __builtin_ctzll(vb) : 0, 64);
+        const long long g0 = t_first / S2_GROUP;
+        int c0 = (store && t / S2_GROUP == g0) ? nnz_t : 0, c1 = (store && t / S2_GROUP != g0) ? nnz_t : 0;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            c0 += __shfl_xor(c0, d, 64);
+            c1 += __shfl_xor(c1, d, 64);
+        }
+        if (lane == 0 && vb) {
+            if (c0) atomicAdd(&group_nnz[g0], c0);
+            if (c1) atomicAdd(&group_nnz[g0 + 1], c1);
+        }
+    }
+    if (!store) return;
+    c_colidx[t] = col;
+    pairs_offset[t] = p0;
+    // reference packing: word q = (row 2q) << 16 | row 2q+1  (spgemm.cu:533-543)
+    *reinterpret_cast<uint4 *>(c_mask + 8 * t) = make_uint4((cw[0] << 16) | (cw[0] >> 16), (cw[1] << 16) | (cw[1] >> 16),
+                                                            (cw[2] << 16) | (cw[2] >> 16), (cw[3] << 16) | (cw[3] >> 16));
+    *reinterpret_cast<uint4 *>(c_mask + 8 * t + 4) = make_uint4((cw[4] << 16) | (cw[4] >> 16), (cw[5] << 16) | (cw[5] >> 16),
+                                                                (cw[6] << 16) | (cw[6] >> 16), (cw[7] << 16) | (cw[7] >> 16));
+}
+
+// a11's offsets + a12 (spgemm.cu:546, 1288, 552-591), one C tile per lane, S2_GROUP tiles per block: entry offsets =
+// the group's base (scanned group counts) + a block scan of the masks' popcounts; the (r<<4|c) bytes; and, for step 3,
+// the tile every S3_CHUNK-entry chunk of C starts in.
+__global__ void __launch_bounds__(S2_GROUP) s2_entries_kernel(const uint32_t *__restrict__ c_mask, long long ntc, const int *__restrict__ group_base,
+                                                              long long cap_nnz, int *__restrict__ c_tile_nnz_ptr, uint8_t *__restrict__ c_rowcolidx,
+                                                              int *__restrict__ chunk_tile, int *__restrict__ flags)
+{
+    __shared__ int w_nnz[S2_GROUP / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long t = (long long)blockIdx.x * S2_GROUP + tid;
+    unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (t < ntc) {
+        const uint4 M0 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t);
+        const uint4 M1 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t + 4);
+        const unsigned w[8] = {M0.x, M0.y, M0.z, M0.w, M1.x, M1.y, M1.z, M1.w};   // word q = (row 2q) << 16 | row 2q+1
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cw[q] = (w[q] << 16) | (w[q] >> 16);          // natural layout
+    }
+    int nnz_t = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) nnz_t += __popc(cw[q]);
     int inc = nnz_t;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const int o = __shfl_up(inc, d, 64);
         if (lane >= d) inc += o;
     }
-    if (lane == 63) {
-        w_tiles[wave] = __popcll(vb);
-        w_nnz[wave] = inc;
-    }
+    if (lane == 63) w_nnz[wave] = inc;
     __syncthreads();
-    int tile_off = tile_rank_w, nnz_off = inc - nnz_t, blk_tiles = 0, blk_nnz = 0;
+    long long off = (long long)group_base[blockIdx.x] + inc - nnz_t;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        if (w < wave) {
-            tile_off += w_tiles[w];
-            nnz_off += w_nnz[w];
-        }
-        blk_tiles += w_tiles[w];
-        blk_nnz += w_nnz[w];
+    for (int w = 0; w < S2_GROUP / 64; ++w)
+        if (w < wave) off += w_nnz[w];
+    if (t > ntc) return;
+    if (t == ntc) {                       // closing offset = C_nnz
+        c_tile_nnz_ptr[ntc] = (int)off;
+        return;
     }
-    // decoupled look-back: exclusive prefix of this block over all earlier tickets
-    if (wave == 0) {
-        const unsigned long long agg = (unsigned long long)blk_tiles | ((unsigned long long)blk_nnz << 31);
-        unsigned long long excl = 0;
-        if (blk == 0) {
-            if (lane == 0) __hip_atomic_store(&lb_state[0], (agg << 2) | LB_PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (lane == 0) __hip_atomic_store(&lb_state[blk], (agg << 2) | LB_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int look = blk - 1, polls = 0;
-            while (true) {
-                const int idx = look - lane;
-                const unsigned long long v = idx >= 0 ? __hip_atomic_load(&lb_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_PREFIX;
-                const unsigned st = (unsigned)(v & 3ull);
-                const unsigned long long inv = __ballot(st == 0), pre = __ballot(st == 2);
-                const unsigned long long usable = inv ? ((inv & (~inv + 1ull)) - 1ull) : ~0ull;   // lanes nearer than the first unpublished block
-                const unsigned long long hit = pre & usable;
-                if (hit || !inv) {
-                    const int last = hit ? __builtin_ctzll(hit) : 63;                            // nearest block holding an inclusive prefix
-                    unsigned long long c = lane <= last ? (v >> 2) : 0ull;
-#pragma unroll
-                    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
-                    excl += c;
-                    if (hit) break;
-                    look -= 64;
-                    continue;
-                }
-                if (++polls > LB_POLL_BUDGET) {   // cannot happen (see the header); never hang the device on a protocol bug
-                    if (lane == 0) flags[FLAG_CAPACITY] = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            if (lane == 0) __hip_atomic_store(&lb_state[blk], ((excl + agg) << 2) | LB_PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (lane == 0) s_excl = excl;
-    }
-    __syncthreads();
-    const unsigned long long excl = s_excl;
-    const long long tile_base = (long long)(excl & 0x7FFFFFFFull), nnz_base = (long long)(excl >> 31);
-    const long long t = tile_base + tile_off, off = nnz_base + nnz_off;
-    if (tid == 255) {   // inclusive prefix of the block (lane 255 holds the last offsets)
-        const long long tiles_incl = tile_base + blk_tiles, nnz_incl = nnz_base + blk_nnz;
-        if (nnz_incl > 0x7FFFFFFFll) flags[FLAG_OVERFLOW] = 1;
-        if (tiles_incl > cap_tiles || (WRITE_RC && nnz_incl > cap_nnz)) flags[FLAG_CAPACITY] = 1;
-        if ((long long)(blk + 1) * 256 >= nslots) {   // the block holding the last slot: totals and the closing offsets
-            d_scalars[1] = tiles_incl;
-            d_scalars[2] = nnz_incl;
-            if (tiles_incl <= cap_tiles) {
-                pairs_offset[tiles_incl] = (int)nslots;
-                c_tile_nnz_ptr[tiles_incl] = (int)nnz_incl;
-            }
-        }
-    }
-    if (!valid || t >= cap_tiles) return;
-    c_colidx[t] = col;
-    pairs_offset[t] = p0;
     c_tile_nnz_ptr[t] = (int)off;
-    // reference packing: word q = (row 2q) << 16 | row 2q+1  (spgemm.cu:533-543)
-    *reinterpret_cast<uint4 *>(c_mask + 8 * t) = make_uint4((cw[0] << 16) | (cw[0] >> 16), (cw[1] << 16) | (cw[1] >> 16),
-                                                            (cw[2] << 16) | (cw[2] >> 16), (cw[3] << 16) | (cw[3] >> 16));
-    *reinterpret_cast<uint4 *>(c_mask + 8 * t + 4) = make_uint4((cw[4] << 16) | (cw[4] >> 16), (cw[5] << 16) | (cw[5] >> 16),
-                                                                (cw[6] << 16) | (cw[6] >> 16), (cw[7] << 16) | (cw[7] >> 16));
-    if constexpr (WRITE_RC) {
-        if (off + nnz_t <= cap_nnz) {
-            // step 3 deals C entries in chunks of S3_CHUNK: note the tile every chunk starts in (saves its waves a search)
-            for (long long ch = (off + S3_CHUNK - 1) / S3_CHUNK; ch * S3_CHUNK < off + nnz_t; ++ch) chunk_tile[ch] = (int)t;
-            s2_emit_rowcol(cw, c_rowcolidx + off);
-        }
+    if (off + nnz_t > cap_nnz) {          // cannot happen: the host sized the buffers from the same counts
+        flags[FLAG_CAPACITY] = 1;
+        return;
     }
+    // step 3 deals C entries in chunks of S3_CHUNK: note the tile every chunk starts in (saves its waves a search)
+    for (long long ch = (off + S3_CHUNK - 1) / S3_CHUNK; ch * S3_CHUNK < off + nnz_t; ++ch) chunk_tile[ch] = (int)t;
+    s2_emit_rowcol(cw, c_rowcolidx + off);
 }
 
 // Ctiles_rowPtr (spgemm.cu:579-580) from the stored masks, one C tile per lane.  Nothing on the default path reads
@@ -1145,41 +1145,6 @@ __global__ void __launch_bounds__(256) s2_crowptr_kernel(const uint32_t *__restr
         run += __popc(w[q] & 0xFFFFu);
     }
     *reinterpret_cast<uint4 *>(c_rowptr + 16 * t) = make_uint4(rp[0], rp[1], rp[2], rp[3]);
-}
-
-// a12 (spgemm.cu:582-587): packed (r<<4|c) bytes, one C tile per lane (first pass on a plan: the entry total is
-// only known once the fused kernel above has run, so the bytes follow in a launch of their own)
-__global__ void __launch_bounds__(256) s2_crowcol_wide_kernel(const uint32_t *__restrict__ c_mask, const int *__restrict__ c_tile_nnz_ptr,
-                                                              long long ntc, uint8_t *__restrict__ c_rowcolidx, int *__restrict__ chunk_tile)
-{
-    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntc) return;
-    const uint4 M0 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t);
-    const uint4 M1 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t + 4);
-    const unsigned w[8] = {M0.x, M0.y, M0.z, M0.w, M1.x, M1.y, M1.z, M1.w};
-    const int off = c_tile_nnz_ptr[t];
-    {   // step 3 deals C entries in chunks of S3_CHUNK: note the tile every chunk starts in (saves its waves a search)
-        int nnz_t = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) nnz_t += __popc(w[q]);
-        for (int ch = (off + S3_CHUNK - 1) / S3_CHUNK; ch * S3_CHUNK < off + nnz_t; ++ch) chunk_tile[ch] = (int)t;
-    }
-    uint8_t *dst = c_rowcolidx + off;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        unsigned m = w[q] >> 16;              // row 2q
-        while (m) {
-            int c = __builtin_ctz(m);
-            m &= m - 1;
-            *dst++ = (uint8_t)(((2 * q) << 4) | c);
-        }
-        m = w[q] & 0xFFFFu;                   // row 2q+1
-        while (m) {
-            int c = __builtin_ctz(m);
-            m &= m - 1;
-            *dst++ = (uint8_t)(((2 * q + 1) << 4) | c);
-        }
-    }
 }
 
 // a13 (spgemm.cu:593-661): one C entry per lane.  A wave owns 64 consecutive C tiles; their
@@ -1207,7 +1172,7 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     const long long eb = wave * S3_EPW;
     if (eb >= nnz_c) return;
     const int e_lo = (int)eb, e_hi = (int)(eb + S3_EPW < nnz_c ? eb + S3_EPW : nnz_c);
-    const long long lo = chunk_tile[wave];   // the tile entry e_lo lies in (noted by s2_crowcol_wide_kernel)
+    const long long lo = chunk_tile[wave];   // the tile entry e_lo lies in (noted by s2_entries_kernel)
     for (long long t0 = lo; t0 < ntc; t0 += 64) {
         const long long tl = t0 + lane < ntc ? t0 + lane : ntc - 1;
         const int my_off = (t0 + lane < ntc) ? c_tile_nnz_ptr[tl] : 0x7FFFFFFF;   // value offset of tile t0+lane
@@ -1629,7 +1594,8 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
                          rl + (size_t)(BIN) * mt, counts[BIN], A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, A->tile_colidx.as<int>(), \
                          p->aprod_off.as<int>(), p->lprod_off.as<int>(), B->tile_rowptr.as<int>(), B->tile_colidx.as<int>(),         \
                          A->tile_occ.as<uint32_t>(), B->tile_occ.as<uint32_t>(), prune, p->pairs_a.as<int>(), p->pairs_b.as<int>(),   \
-                         p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->c_tile_rowptr.as<int>(), key_bits);                   \
+                         p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->block_info.as<int2>(), p->c_tile_rowptr.as<int>(),     \
+                         key_bits);                                                                                                    \
     }
     // The bins are independent and run concurrently: the largest non-empty one on the main stream, the others
     // forked onto auxiliary streams and joined before the row-count scan.  Order matters: a block of the 32768-key
@@ -1758,6 +1724,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->pairs_b.reserve(sizeof(int) * (n + 4)));
         PEM_TRY(p->scratch_col.reserve(sizeof(int) * (n + 4)));
         PEM_TRY(p->scratch_off.reserve(sizeof(int) * (n + 4)));
+        PEM_TRY(p->block_info.reserve(sizeof(int2) * (n / 256 + 4)));
         if (k32)
             launch_rowsorts<uint32_t>(ctx, p, counts, mt, cap3, prune);
         else
@@ -1786,7 +1753,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
             PEM_LAUNCH(ctx, s1_xl_emit_kernel, grid_for(n_xl, 256), 256, keys, perm, head.as<int>(), n_xl, bits_tc, p->xl_rowstart.as<int>(),
                        A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->lprod_off.as<int>(), p->prod_a.as<int>(), p->prod_b.as<int>(),
                        p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(),
-                       p->c_tile_rowptr.as<int>());
+                       p->block_info.as<int2>(), p->c_tile_rowptr.as<int>());
         }
         // _C_rowPtr = exclusive scan of the per-row tile counts (spgemm.cu:1168); total = T_C
         PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_rowptr.as<int>(), p->c_tile_rowptr.as<int>(), (size_t)mt, ctx->d_scalars + 1));
@@ -1864,34 +1831,33 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
         PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
         if (n > 0) {
-            const size_t nblk = (n + 255) / 256;
-            PEM_TRY(p->lb_state.reserve(sizeof(unsigned long long) * (nblk + 2)));
-            PEM_HIP(hipMemsetAsync(p->lb_state.p, 0, sizeof(unsigned long long) * (nblk + 2), st));
-            unsigned long long *lb = p->lb_state.as<unsigned long long>();
-            int *ticket = reinterpret_cast<int *>(lb + nblk);
-            if (p->warm_pass) {   // sizes known: the (r<<4|c) bytes and step 3's chunk index come out of the same launch
+            // entry counts of every S2_GROUP tiles, accumulated by s2_tiles_kernel
+            const size_t nblk = (n + 255) / 256, ngroups = (ntc + S2_GROUP - 1) / S2_GROUP;
+            PEM_TRY(p->group_nnz.reserve(sizeof(int) * (ngroups + 4)));
+            PEM_HIP(hipMemsetAsync(p->group_nnz.p, 0, sizeof(int) * (ngroups + 4), st));
+            int *group_nnz = p->group_nnz.as<int>();
+            PEM_LAUNCH(ctx, s2_tiles_kernel, (unsigned)nblk, 256, p->scratch_col.as<int>(), p->scratch_off.as<int>(), (long long)n,
+                       p->block_info.as<int2>(), p->c_tile_rowptr.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), A->masks.as<uint16_t>(),
+                       B->masks.as<uint16_t>(), (long long)ntc, p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>(), p->c_mask.as<uint32_t>(),
+                       group_nnz);
+            PEM_TRY(exclusive_scan_i32(ctx, group_nnz, group_nnz, ngroups, ctx->d_scalars + 2));
+            if (p->warm_pass) {
                 nnzc = p->w_nnz;
-                PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
-                PEM_TRY(p->s3_chunk_tile.reserve(sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)));
-                PEM_LAUNCH_NAMED(ctx, "s2_tiles_kernel<rc>", s2_tiles_kernel<true>, (unsigned)nblk, 256, p->scratch_col.as<int>(), p->scratch_off.as<int>(),
-                                 (long long)n, p->pairs_a.as<int>(), p->pairs_b.as<int>(), A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), lb, ticket,
-                                 (long long)ntc, (long long)nnzc, p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>(), p->c_mask.as<uint32_t>(),
-                                 p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->s3_chunk_tile.as<int>(),
-                                 reinterpret_cast<long long *>(ctx->d_scalars), ctx->d_flags);
             } else {
-                PEM_LAUNCH_NAMED(ctx, "s2_tiles_kernel", s2_tiles_kernel<false>, (unsigned)nblk, 256, p->scratch_col.as<int>(), p->scratch_off.as<int>(),
-                                 (long long)n, p->pairs_a.as<int>(), p->pairs_b.as<int>(), A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), lb, ticket,
-                                 (long long)ntc, 0ll, p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>(), p->c_mask.as<uint32_t>(),
-                                 p->c_tile_nnz_ptr.as<int>(), (uint8_t *)nullptr, (int *)nullptr, reinterpret_cast<long long *>(ctx->d_scalars),
-                                 ctx->d_flags);
-                int64_t sc[2];
-                PEM_TRY(read_scalars(ctx, ctx->d_scalars + 1, 2, sc));
-                if (sc[0] != (int64_t)ntc) {
-                    set_error("step 2: %lld C tiles found, step 1 counted %zu", (long long)sc[0], ntc);
-                    return PEM_E_STATE;
+                int64_t sc[1];
+                PEM_TRY(read_scalars(ctx, ctx->d_scalars + 2, 1, sc));
+                int hf[NUM_FLAGS];
+                PEM_TRY(read_flags(ctx, hf));
+                if (hf[FLAG_OVERFLOW] || sc[0] > 0x7FFFFFFFll) {
+                    set_error("step 2: C has more than 2^31-1 nonzeros, beyond the int32 range of the reference's offsets");
+                    return PEM_E_OVERFLOW;
                 }
-                nnzc = sc[1];
+                nnzc = sc[0];
             }
+            PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
+            PEM_TRY(p->s3_chunk_tile.reserve(sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)));
+            PEM_LAUNCH(ctx, s2_entries_kernel, (unsigned)((ntc + S2_GROUP) / S2_GROUP), S2_GROUP, p->c_mask.as<uint32_t>(), (long long)ntc, group_nnz,
+                       (long long)nnzc, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->s3_chunk_tile.as<int>(), ctx->d_flags);
             p->compact_valid = true;
         } else {
             PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_nnz_ptr.as<int>(), p->c_tile_nnz_ptr.as<int>(), 0, ctx->d_scalars + 2));
@@ -1913,15 +1879,13 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
         }
     }
     if (!p->warm_pass) {
-        int hf[NUM_FLAGS];
-        PEM_TRY(read_flags(ctx, hf));
-        if (hf[FLAG_OVERFLOW] || nnzc > 0x7FFFFFFFll) {
-            set_error("step 2: C has more than 2^31-1 nonzeros, beyond the int32 range of the reference's offsets");
-            return PEM_E_OVERFLOW;
-        }
-        if (hf[FLAG_CAPACITY]) {
-            set_error("step 2: the C tile scan did not complete");
-            return PEM_E_STATE;
+        if (!fused) {
+            int hf[NUM_FLAGS];
+            PEM_TRY(read_flags(ctx, hf));
+            if (hf[FLAG_OVERFLOW] || nnzc > 0x7FFFFFFFll) {
+                set_error("step 2: C has more than 2^31-1 nonzeros, beyond the int32 range of the reference's offsets");
+                return PEM_E_OVERFLOW;
+            }
         }
         p->w_nnz = nnzc;
     }
@@ -1929,9 +1893,6 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
     PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
     PEM_TRY(p->s3_chunk_tile.reserve(sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)));
     PEM_TRY(p->c_vals.reserve((size_t)A->value_bytes * ((size_t)nnzc + 1)));
-    if (ntc > 0 && fused && !p->warm_pass)
-        PEM_LAUNCH(ctx, s2_crowcol_wide_kernel, grid_for(ntc, 256), 256, p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
-                   p->c_rowcolidx.as<uint8_t>(), p->s3_chunk_tile.as<int>());
     if (ntc > 0 && !fused) {   // the 16-lanes-per-tile baseline writes Ctiles_rowPtr as it goes, like the reference (spgemm.cu:579-580)
         PEM_TRY(p->c_rowptr.reserve(16 * (ntc + 1)));
         PEM_LAUNCH(ctx, s2_crowcol_kernel, grid_for(ntc * 16, 256), 256, p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,

@@ -16,6 +16,35 @@ def slice_bounds(bounds, rank):
     return int(bounds[rank]), int(bounds[rank + 1])
 
 
+def row_bounds_from_transpose(b_tile_rowptr, b_tile_colptr, b_tile_rowidx, nparts):
+    """pem_split_tile_rows for A = B^T without tiling A: A's tile (i, k) exists iff B's tile (k, i) does, so tile
+    row i of A is tile column i of B (read off B's tile CSC) and its product count is the sum of the lengths of
+    B's tile rows k over that column.  Same weights and cut rule as the device routine (products + tiles + 1)."""
+    import numpy as np
+    blen = np.diff(np.asarray(b_tile_rowptr, dtype=np.int64))
+    colptr = np.asarray(b_tile_colptr, dtype=np.int64)
+    mt = len(colptr) - 1
+    col_of = np.repeat(np.arange(mt), np.diff(colptr))
+    w = np.bincount(col_of, weights=blen[np.asarray(b_tile_rowidx, dtype=np.int64)], minlength=mt) + np.diff(colptr) + 1.0
+    pre = np.concatenate([[0.0], np.cumsum(w)])
+    bounds, row = [0], 0
+    for g in range(1, nparts):
+        target = pre[mt] * g / nparts
+        while row < mt and pre[row + 1] <= target:
+            row += 1
+        bounds.append(row)
+    bounds.append(mt)
+    return np.asarray(bounds, dtype=np.int32)
+
+
+def _drain(t):
+    """Block the host until the communication just waited on has really finished.  Under RCCL `req.wait()` only makes
+    torch's current stream wait; the library exports into the send buffers on ITS OWN stream, so the next pass's export
+    must not start before the transfer that reads them is done (gloo's wait() already blocks the host)."""
+    if t.is_cuda:
+        torch.cuda.current_stream(t.device).synchronize()
+
+
 def gather_csr_slices(rowptr, colidx, vals, dst=0, group=None):
     """Gather per-rank CSR row slices (rowptr relative, starting at 0) into one CSR on `dst`.
 
@@ -40,6 +69,7 @@ def gather_csr_slices(rowptr, colidx, vals, dst=0, group=None):
             ops.append(dist.P2POp(dist.isend, vals, dst, group=group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        _drain(rowptr)
         return None
     tot_rows, tot_nnz = sum(nrows), sum(nnzs)
     out_rp = torch.zeros(tot_rows + 1, dtype=torch.int32, device=dev)
@@ -69,6 +99,7 @@ def gather_csr_slices(rowptr, colidx, vals, dst=0, group=None):
     for r in range(world):   # rebase the relative row pointers by the nnz offset of the slice
         ro, no = offs[r]
         out_rp[ro + 1:ro + nrows[r] + 1] = rp_parts[r][1:] + no
+    _drain(out_rp)               # the copies out of the caller's colidx / vals are done before it may re-export into them
     return out_rp, out_ci, out_v
 
 
@@ -164,6 +195,7 @@ def gather_csr_blocks(rowptr, colidx, vals, ncol_blocks, dst=0, group=None):
             ops.append(dist.P2POp(dist.isend, vals, dst, group=group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        _drain(rowptr)
         return None
     blocks, ops = [], []
     for r in range(world):
@@ -181,7 +213,9 @@ def gather_csr_blocks(rowptr, colidx, vals, ncol_blocks, dst=0, group=None):
     if ops:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-    return assemble_csr_blocks(blocks, ncol_blocks)
+    out = assemble_csr_blocks(blocks, ncol_blocks)
+    _drain(out[0])
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -268,7 +302,11 @@ class ChunkedRowBlock:
                 works += self._post(c)
         for w in works:
             w.wait()
-        return self._assemble()
+        out = self._assemble()
+        # every send that reads this pass's export buffers, and the root's copies out of them, are finished before the
+        # next pass exports into the same buffers on the library's stream
+        torch.cuda.current_stream().synchronize()
+        return out
 
     def _post(self, c):
         ops = []

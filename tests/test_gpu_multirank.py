@@ -12,10 +12,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(n, extra):
+def _run(n, extra, launcher=True):
+    """launcher=True: under torch.distributed.run, the driver's form; False: `python bench.py --gpus N` as typed, bench.py
+    starts its own ranks as a child process"""
     env = dict(os.environ, PEM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None)
     cmd = [sys.executable]
-    if n > 1:
+    if n > 1 and launcher:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", "29571"]
     cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
@@ -31,6 +34,20 @@ def test_two_ranks_on_one_card_agree_with_one_rank():
     for k in ("flop", "C_nnz", "C_tiles", "tile_pairs", "nnz"):
         assert one["config"][k] == two["config"][k], k
     assert two["value"] > 0 and two["scaling"] == "strong"
+    # the same typed plainly: bench.py generates the input once, shares it and launches its own two ranks
+    plain = _run(2, ["--workload", "scircuit", "--scale", "0.25"], launcher=False)
+    assert plain["n_gpus"] == 2 and plain["exchange"]["gathered"] == two["exchange"]["gathered"]
+    assert plain["exchange"]["ms_per_step"] > 0 and plain["exchange"]["bytes_to_root"] > 0
+
+
+def test_two_ranks_a_at_row_blocks_tile_only_their_rows():
+    """A*A^T on two ranks: B = A^T whole on both, each rank tiles only its own row block of A (cut from the COO with
+    boundaries read off B's tile CSC); flop, sizes and the gathered C equal the one-rank run."""
+    one = _run(1, ["--workload", "mc2depi", "--scale", "0.05"])
+    two = _run(2, ["--workload", "mc2depi", "--scale", "0.05"], launcher=False)
+    for k in ("flop", "C_nnz", "C_tiles", "tile_pairs", "nnz"):
+        assert one["config"][k] == two["config"][k], k
+    assert two["exchange"]["gathered"]["nnz"] == one["config"]["C_nnz"]
 
 
 def test_grid_partition_on_one_card_gathers_the_same_matrix():

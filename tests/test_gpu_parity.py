@@ -215,3 +215,4 @@ def test_options_are_latched_at_plan_creation(pkg, oracle, ctx, monkeypatch):
     plan2 = pkg.CPlan(ctx, gA, gB)                        # a new plan sees the new value
     plan2.spgemm()
     assert plan2.info()["npairs"] == op.npairs
+
