@@ -209,6 +209,9 @@ struct pem_cplan {
     // step-1 products kept for step 2 (expanded pair ids + the sorted permutation)
     pem::DevBuf prod_a, prod_b, aprod_off;
     pem::DevBuf lprod_off;             // like aprod_off, counting only products whose tiles can meet (live products)
+    // (row-local step 1 keeps per-A-tile COUNTS in the two buffers above; only the global-sort path scans them)
+    pem::DevBuf row_n, row_lbase;      // per tile row: all products; live products -> exclusive scan = the row's first pair / C tile slot
+    pem::DevBuf xl_lrel;               // oversized rows only: live offset of every A tile relative to its row
     int64_t npairs_all = 0;            // all tile-level products (the reference's P) -- npairs counts the live ones
     pem::DevBuf sk0, sk1, sv0, sv1;    // sort buffers
     uint32_t *sorted_perm = nullptr;   // points into sv0/sv1
@@ -228,4 +231,5 @@ struct pem_cplan {
     int64_t w_P = 0, w_Pall = 0, w_TC = 0, w_nnz = 0;
     int w_counts[4] = {0, 0, 0, 0};
     int64_t w_nxl = 0;
+    int w_nrows_xl = 0;
 };

@@ -34,7 +34,9 @@ using namespace pem;
 // the reference's lists exactly.  16 lanes per A tile: aprod = all products, lprod = live products.
 __global__ void __launch_bounds__(256) s1_aprod_kernel(const int *__restrict__ a_tile_colidx, const uint32_t *__restrict__ a_occ, int a_lo,
                                                        int nA, const int *__restrict__ b_tile_rowptr, const uint32_t *__restrict__ b_occ,
-                                                       int prune, int *__restrict__ aprod, int *__restrict__ lprod)
+                                                       int prune, int *__restrict__ aprod, int *__restrict__ lprod,
+                                                       const long long *__restrict__ a_tile_keys, int tr_lo, int *__restrict__ row_n,
+                                                       int *__restrict__ row_l)
 {
     constexpr int G = 8;        // lanes per A tile (B tile rows average ~34 tiles; 16 lanes: 88 us, 8: 59 us, 4: 58 us)
     const int arel = (blockIdx.x * blockDim.x + threadIdx.x) / G;
@@ -53,9 +55,35 @@ __global__ void __launch_bounds__(256) s1_aprod_kernel(const int *__restrict__ a
     }
 #pragma unroll
     for (int d = G / 2; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, G);
+    if (!prune) cnt = len;
     if (in && l == 0) {
         aprod[arel] = len;
-        lprod[arel] = prune ? cnt : len;
+        lprod[arel] = cnt;
+    }
+    // Per tile-row totals (row-local step 1: the rows' product counts are all the scan that is left -- the offsets of
+    // the A tiles inside a row are rebuilt in LDS by the row's own workgroup).  The wave's eight A tiles are
+    // consecutive, so tiles of one row sit next to each other: the first of each run adds the run's sums, one atomic
+    // pair per run (a hub row of 4 700 A tiles: 590 adds on its two counters instead of 4 700).
+    if (row_n == nullptr) return;
+    const int row = in ? (int)(a_tile_keys[a_lo + arel] >> 32) - tr_lo : -1 - (int)(threadIdx.x / G);   // distinct dummies never merge
+    const int lane = threadIdx.x & 63;
+    // suffix sums over the run, by doubling: tiles are sorted by row, so "the tile d further on has my row" implies the
+    // ones in between have it too, and its partial sum only ever covers tiles of that same row
+    int sum_n = len, sum_l = cnt;
+#pragma unroll
+    for (int d = 1; d < 64 / G; d <<= 1) {
+        const int src = lane + d * G;
+        const int orow = __shfl(row, src & 63, 64), on = __shfl(sum_n, src & 63, 64), ol = __shfl(sum_l, src & 63, 64);
+        if (src < 64 && orow == row) {
+            sum_n += on;
+            sum_l += ol;
+        }
+    }
+    const int prow = __shfl(row, (lane - G) & 63, 64);
+    const bool head = in && l == 0 && (lane < G || prow != row);
+    if (head) {
+        atomicAdd(&row_n[row], sum_n);
+        atomicAdd(&row_l[row], sum_l);
     }
 }
 
@@ -80,10 +108,10 @@ __global__ void __launch_bounds__(256) s1_xl_expand_kernel(const long long *__re
         const long long ak = a_tile_keys[a];
         i = (int)(ak >> 32) - tr_lo;
         k = (int)(ak & 0xFFFFFFFFll);
-        if (xl_base) {
+        if (xl_base) {          // lprod_off: live offsets relative to the row (s1_xl_rel_kernel), only valid in oversized rows
             const int base = xl_base[i];
-            if (base >= 0) x0 = base + (lprod_off[arel] - lprod_off[a_tile_rowptr[tr_lo + i] - a_lo]);
-        } else {
+            if (base >= 0) x0 = base + lprod_off[arel];
+        } else {                // global live offsets (PEM_STEP1=esc)
             x0 = lprod_off[arel];
         }
         if (x0 >= 0) {
@@ -166,12 +194,14 @@ __global__ void s1_c_rowptr_kernel(const int *__restrict__ c_rowidx, long long n
 // counts have been scanned.
 // ------------------------------------------------------------------------------------------
 constexpr int S1_CAP0 = 512, S1_CAP1 = 2048, S1_CAP2 = 8192, S1_CAP3 = 32768;
+constexpr int S1_RCAP0 = 256, S1_RCAP1 = 1024, S1_RCAP2 = 2048, S1_RCAP3 = 1024;   // A tiles per row a bin's LDS table holds
 constexpr int S1_COARSE = 512;   // 64-product blocks indexed per row (covers the 32768 products a 15-bit index field allows)
 
-__global__ void s1_reset_kernel(int *__restrict__ flags, int *__restrict__ bin_count, long long *__restrict__ scalars,
-                                int *__restrict__ pairs_offset, int *__restrict__ row_tc, int mt)
+__global__ void __launch_bounds__(256) s1_reset_kernel(int *__restrict__ flags, int *__restrict__ bin_count, long long *__restrict__ scalars,
+                                                       int *__restrict__ pairs_offset, int *__restrict__ row_tc, int mt, int *__restrict__ row_n,
+                                                       int *__restrict__ row_l)
 {
-    const int i = threadIdx.x;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < NUM_FLAGS) flags[i] = 0;
     if (i < 8) bin_count[i] = 0;
     if (i < 4) scalars[i] = 0;
@@ -179,35 +209,47 @@ __global__ void s1_reset_kernel(int *__restrict__ flags, int *__restrict__ bin_c
         pairs_offset[0] = 0;
         row_tc[mt] = 0;
     }
+    if (i <= mt) {              // per-row product totals, accumulated by s1_aprod_kernel
+        row_n[i] = 0;
+        row_l[i] = 0;
+    }
 }
 
-__global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int mt, int a_lo,
-                                                          const int *__restrict__ aprod_off, const int *__restrict__ lprod_off, int cap3,
+__global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int mt,
+                                                          const int *__restrict__ row_n, const int *__restrict__ row_lbase, int cap3,
                                                           int qcap, int xlcap, int *__restrict__ row_list,
-                                                          int *__restrict__ bin_count, int *__restrict__ xl_base, int *__restrict__ row_tc)
+                                                          int *__restrict__ bin_count, int *__restrict__ xl_base, int *__restrict__ row_tc,
+                                                          long long *__restrict__ scalars)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    int n = 0, nl = 0;
+    int n = 0, nl = 0, R = 0;
     if (i < mt) {
-        int a0 = a_tile_rowptr[tr_lo + i] - a_lo, a1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
-        n = aprod_off[a1] - aprod_off[a0];
-        nl = lprod_off[a1] - lprod_off[a0];
+        R = a_tile_rowptr[tr_lo + i + 1] - a_tile_rowptr[tr_lo + i];
+        n = row_n[i];
+        nl = row_lbase[i + 1] - row_lbase[i];
         xl_base[i] = -1;
         row_tc[i] = 0;
     }
-    // bins by LIVE products (what gets sorted); the key's index field must still hold every product of the row
-    const int bin = nl == 0 ? -1 : (n > qcap || nl > xlcap) ? 4 : nl <= S1_CAP0 ? 0 : nl <= S1_CAP1 ? 1 : nl <= S1_CAP2 ? 2 : nl <= cap3 ? 3 : 4;
+    // bins by LIVE products (what gets sorted); the key's index field must still hold every product of the row, and the
+    // bin's LDS table every A tile of the row (a row with more A tiles moves up, or to the global path)
+    int bin = nl == 0 ? -1 : (n > qcap || nl > xlcap) ? 4 : nl <= S1_CAP0 ? 0 : nl <= S1_CAP1 ? 1 : nl <= S1_CAP2 ? 2 : nl <= cap3 ? 3 : 4;
+    if (bin == 0 && R > S1_RCAP0) bin = 1;
+    if (bin == 1 && R > S1_RCAP1) bin = 2;
+    if (bin == 2 && R > S1_RCAP2) bin = 4;
+    if (bin == 3 && R > S1_RCAP3) bin = 4;
     // slots by ballot + prefix popcount inside a wave, one LDS atomic per wave and bin inside the block, ONE global
     // atomic per block and bin (order inside a bin is irrelevant): 4 k wave-level atomics on four counters serialised
     // for ~20 us of a 33 us kernel
-    __shared__ int blk_cnt[4], blk_base[4];
-    if (threadIdx.x < 4) blk_cnt[threadIdx.x] = 0;
+    __shared__ int blk_cnt[5], blk_base[5];
+    __shared__ long long blk_all;
+    if (threadIdx.x < 5) blk_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) blk_all = 0;
     __syncthreads();
     int wbase = 0, rank = 0;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < 5; ++b) {
         const unsigned long long m = __ballot(bin == b);
         if (m == 0) continue;
         const int leader = __builtin_ctzll(m);
@@ -219,11 +261,55 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
             rank = __popcll(m & lt);
         }
     }
+    {   // every tile-level product of the slice (the reference's P), 64-bit: one atomic per block
+        long long wn = n;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) wn += __shfl_xor(wn, d, 64);
+        if (lane == 0 && wn) atomicAdd(reinterpret_cast<unsigned long long *>(&blk_all), (unsigned long long)wn);
+    }
     __syncthreads();
-    if (threadIdx.x < 4) blk_base[threadIdx.x] = blk_cnt[threadIdx.x] ? atomicAdd(&bin_count[threadIdx.x], blk_cnt[threadIdx.x]) : 0;
+    if (threadIdx.x < 5) blk_base[threadIdx.x] = blk_cnt[threadIdx.x] ? atomicAdd(&bin_count[threadIdx.x], blk_cnt[threadIdx.x]) : 0;
+    if (threadIdx.x == 0 && blk_all) atomicAdd(reinterpret_cast<unsigned long long *>(&scalars[3]), (unsigned long long)blk_all);
     __syncthreads();
-    if (bin >= 0 && bin < 4) row_list[(size_t)bin * mt + blk_base[bin] + wbase + rank] = i;
+    if (bin >= 0) row_list[(size_t)bin * mt + blk_base[bin] + wbase + rank] = i;
     if (bin == 4) xl_base[i] = atomicAdd(&bin_count[5], nl);   // oversized rows are few
+}
+
+// oversized rows (global path): live-product offsets of the row's A tiles relative to the row, one block per row
+__global__ void __launch_bounds__(256) s1_xl_rel_kernel(const int *__restrict__ xl_rows, int nrows_xl, const int *__restrict__ a_tile_rowptr, int tr_lo,
+                                                        int a_lo, const int *__restrict__ lcnt, int *__restrict__ lrel)
+{
+    __shared__ int wsum[4];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int li = blockIdx.x; li < nrows_xl; li += gridDim.x) {
+        const int i = xl_rows[li];
+        const int a0 = a_tile_rowptr[tr_lo + i] - a_lo, a1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
+        if (threadIdx.x == 0) carry_s = 0;
+        __syncthreads();
+        for (int x0 = a0; x0 < a1; x0 += 256) {
+            const int x = x0 + threadIdx.x;
+            const int c = x < a1 ? lcnt[x] : 0;
+            int inc = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += o;
+            }
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            int woff = carry_s, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (w < wave) woff += wsum[w];
+                tot += wsum[w];
+            }
+            if (x < a1) lrel[x] = woff + inc - c;
+            __syncthreads();
+            if (threadIdx.x == 0) carry_s += tot;
+            __syncthreads();
+        }
+    }
 }
 
 // largest a in [lo, hi) with off[a] <= x
@@ -313,13 +399,13 @@ struct S1Row {
     const int *roff, *rbs;
     const unsigned *rco;           // occupied columns of every A tile of the row (pruning)
     const int *cstart;             // A tile holding product 64*c, for every 64th product (rows of up to 32768 products)
-    bool staged, coarse;
+    bool coarse;
     // (the one-wave bin has few A tiles per row: its search is short)
     static constexpr bool COARSE_OK = THREADS >= 256;
     static constexpr bool ORDERED = THREADS == 1024;   // live keys compacted in product order (see expand_compact)
-    int R, a0, a1, p0, n, a_lo, prune;
-    const int *a_tile_colidx, *aprod_off, *b_tile_rowptr, *b_tile_colidx;
-    const uint32_t *a_occ, *b_occ;
+    int R, a0, n, a_lo, prune;
+    const int *b_tile_colidx;
+    const uint32_t *b_occ;
     struct Product {
         int a, b;          // operand tile ids
         unsigned acol;     // occupied columns of the A tile
@@ -330,22 +416,15 @@ struct S1Row {
         Product r;
         int ar;
         r.acol = 0xFFFFu;
-        if (staged) {
-            if (COARSE_OK && coarse) {   // a short walk from the tile of the 64-product block instead of a log2(R)-step search
-                ar = cstart[q >> 6];
-                while (roff[ar + 1] <= q) ++ar;
-            } else {
-                ar = s1_find_a(roff, 0, R, q);
-            }
-            r.b = rbs[ar] + (q - roff[ar]);
-            if (want_acol) r.acol = rco[ar];
-            ar += a0;
+        if (COARSE_OK && coarse) {   // a short walk from the tile of the 64-product block instead of a log2(R)-step search
+            ar = cstart[q >> 6];
+            while (roff[ar + 1] <= q) ++ar;
         } else {
-            ar = s1_find_a(aprod_off, a0, a1, p0 + q);
-            r.b = b_tile_rowptr[a_tile_colidx[a_lo + ar]] + (p0 + q - aprod_off[ar]);
-            if (want_acol) r.acol = a_occ[a_lo + ar] & 0xFFFFu;
+            ar = s1_find_a(roff, 0, R, q);
         }
-        r.a = a_lo + ar;
+        r.b = rbs[ar] + (q - roff[ar]);
+        if (want_acol) r.acol = rco[ar];
+        r.a = a_lo + a0 + ar;
         return r;
     }
     // key of product q: (tile col, q); a product whose tiles cannot meet gets the padding key and sorts to the end
@@ -567,7 +646,7 @@ extern "C" void pem_debug_s1(unsigned long long *out32, int reset)
 template <typename KeyT, int CAP, int QB, int THREADS, int RCAP>
 __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || sizeof(KeyT) == 8 ? 4 : 8) : 1) s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr,
                                                              int tr_lo, int a_lo, const int *__restrict__ a_tile_colidx,
-                                                             const int *__restrict__ aprod_off, const int *__restrict__ lprod_off,
+                                                             const int *__restrict__ acnt, const int *__restrict__ row_n, const int *__restrict__ row_lbase,
                                                              const int *__restrict__ b_tile_rowptr, const int *__restrict__ b_tile_colidx,
                                                              const uint32_t *__restrict__ a_occ, const uint32_t *__restrict__ b_occ, int prune,
                                                              int *__restrict__ pairs_a, int *__restrict__ pairs_b,
@@ -606,33 +685,54 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
         row.rbs = rbs;
         row.rco = rco;
         row.prune = prune;
-        row.a_occ = a_occ;
         row.b_occ = b_occ;
         row.a_lo = a_lo;
-        row.a_tile_colidx = a_tile_colidx;
-        row.aprod_off = aprod_off;
-        row.b_tile_rowptr = b_tile_rowptr;
         row.b_tile_colidx = b_tile_colidx;
         row.a0 = a_tile_rowptr[tr_lo + i] - a_lo;
-        row.a1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
-        row.R = row.a1 - row.a0;
-        row.p0 = aprod_off[row.a0];
-        row.n = aprod_off[row.a1] - row.p0;
-        row.staged = row.R <= RCAP;   // the row's A-tile table fits in LDS (else: search it in global memory)
-        const int p0 = row.p0;
-        if (row.staged) {
-            for (int x = tid; x <= row.R; x += THREADS) {
-                roff[x] = aprod_off[row.a0 + x] - p0;
+        row.R = a_tile_rowptr[tr_lo + i + 1] - a_lo - row.a0;   // <= RCAP: the row classification saw to that
+        row.n = row_n[i];
+        {
+            // the row's A-tile table: product counts -> offsets relative to the row (exclusive scan, THREADS entries per
+            // trip -- one trip for all but hub rows), first B tile, occupied columns
+            int carry = 0;
+            for (int x0 = 0; x0 < row.R; x0 += THREADS) {
+                const int x = x0 + tid;
+                int c = 0;
                 if (x < row.R) {
-                    rbs[x] = b_tile_rowptr[a_tile_colidx[a_lo + row.a0 + x]];
-                    rco[x] = a_occ[a_lo + row.a0 + x] & 0xFFFFu;
+                    const int a = a_lo + row.a0 + x;
+                    c = acnt[row.a0 + x];
+                    rbs[x] = b_tile_rowptr[a_tile_colidx[a]];
+                    rco[x] = a_occ[a] & 0xFFFFu;
                 }
+                int inc = c;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int o = __shfl_up(inc, d, 64);
+                    if (lane >= d) inc += o;
+                }
+                int ex = carry + inc - c;
+                if (THREADS > 64 && row.R - x0 > 64) {   // (block-uniform) this trip's entries spill over the first wave
+                    if (lane == 63) wsum[wave] = inc;
+                    __syncthreads();
+                    int tot = 0;
+#pragma unroll
+                    for (int w = 0; w < THREADS / 64; ++w) {
+                        if (w < wave) ex += wsum[w];
+                        tot += wsum[w];
+                    }
+                    carry += tot;
+                    __syncthreads();                      // wsum is re-posted by the next trip
+                } else {
+                    carry += __shfl(inc, 63, 64);         // only wave 0 holds entries; THREADS == 64: the wave's total
+                }
+                if (x < row.R) roff[x] = ex;
             }
+            if (tid == 0) roff[row.R] = row.n;
         }
         row.cstart = cstart;
-        row.coarse = COARSE && row.staged && row.n <= 64 * S1_COARSE;
+        row.coarse = COARSE && row.n <= 64 * S1_COARSE;
+        __syncthreads();
         if (row.coarse) {
-            __syncthreads();
             for (int x = tid; x < row.R; x += THREADS) {      // every 64-product block start inside this A tile's range
                 const int lo = roff[x], hi = roff[x + 1];
                 for (int c = (lo + 63) >> 6; (c << 6) < hi; ++c) cstart[c] = x;
@@ -659,7 +759,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
         // stream out the live products (the dead ones sorted behind them): sorted pairs, and per distinct tile
         // column (C tile) its column + first pair; output positions count live products only
         S1_DBG_MARK(2);
-        const int lp0 = lprod_off[row.a0], nlive = nl;
+        const int lp0 = row_lbase[i], nlive = nl;
         int base = 0;
         for (int s0 = 0; s0 < nlive; s0 += THREADS) {
             const int s = s0 + tid;
@@ -736,8 +836,8 @@ __global__ void s1_xl_rowstart_kernel(const uint64_t *__restrict__ keys, size_t 
 }
 
 __global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm, const int *__restrict__ headx, size_t n,
-                                  int bits_tc, const int *__restrict__ xl_rowstart, const int *__restrict__ a_tile_rowptr, int tr_lo, int a_lo,
-                                  const int *__restrict__ aprod_off, const int *__restrict__ prod_a, const int *__restrict__ prod_b,
+                                  int bits_tc, const int *__restrict__ xl_rowstart, const int *__restrict__ row_lbase,
+                                  const int *__restrict__ prod_a, const int *__restrict__ prod_b,
                                   int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ scratch_col,
                                   int *__restrict__ scratch_off, int2 *__restrict__ block_info, int *__restrict__ row_tc)
 {
@@ -747,8 +847,7 @@ __global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint3
     int i = (int)(key >> bits_tc), j = (int)(key & ((1ull << bits_tc) - 1ull));
     int rs = xl_rowstart[i];
     int s = (int)x - rs;
-    int a0 = a_tile_rowptr[tr_lo + i] - a_lo, a1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
-    int p0 = aprod_off[a0], ni = aprod_off[a1] - p0;
+    int p0 = row_lbase[i], ni = row_lbase[i + 1] - p0;     // the row's live-product (= slot) range
     uint32_t o = perm[x];
     pairs_a[p0 + s] = prod_a[o];
     pairs_b[p0 + s] = prod_b[o];
@@ -771,15 +870,15 @@ __global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint3
 // One block per tile row: the row knows where its tiles go (c_rowptr[i]) and where its scratch lives (its first
 // pair), so the copy is two coalesced streams and needs no search.  (One WAVE per row was as fast on a whole matrix,
 // where the kernel is bandwidth-bound, but left a 1/8 slice -- 8 k rows of ~300 tiles -- latency-bound: 34 us.)
-__global__ void __launch_bounds__(256) s1_compact_kernel(const int *__restrict__ c_rowptr, int mt, long long ntc, int tr_lo,
-                                                         const int *__restrict__ a_tile_rowptr, int a_lo, const int *__restrict__ aprod_off,
+__global__ void __launch_bounds__(256) s1_compact_kernel(const int *__restrict__ c_rowptr, int mt, long long ntc,
+                                                         const int *__restrict__ row_lbase,
                                                          const int *__restrict__ scratch_col, const int *__restrict__ scratch_off, int npairs,
                                                          int *__restrict__ c_colidx, int *__restrict__ pairs_offset)
 {
     for (int i = blockIdx.x; i < mt; i += gridDim.x) {
         const int t0 = c_rowptr[i], cnt = c_rowptr[i + 1] - t0;
         if (cnt == 0) continue;
-        const int p0 = aprod_off[a_tile_rowptr[tr_lo + i] - a_lo];
+        const int p0 = row_lbase[i];
         for (int r = threadIdx.x; r < cnt; r += blockDim.x) {
             c_colidx[t0 + r] = scratch_col[p0 + r];
             pairs_offset[t0 + r] = scratch_off[p0 + r];
@@ -1524,7 +1623,8 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
     PEM_TRY(p->lprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
     if (nA > 0)
         PEM_LAUNCH(ctx, s1_aprod_kernel, grid_for((size_t)nA * 8, 256), 256, A->tile_colidx.as<int>(), A->tile_occ.as<uint32_t>(), p->a_lo, nA,
-                   B->tile_rowptr.as<int>(), B->tile_occ.as<uint32_t>(), prune, p->aprod_off.as<int>(), p->lprod_off.as<int>());
+                   B->tile_rowptr.as<int>(), B->tile_occ.as<uint32_t>(), prune, p->aprod_off.as<int>(), p->lprod_off.as<int>(),
+                   (const long long *)nullptr, 0, (int *)nullptr, (int *)nullptr);
     PEM_TRY(exclusive_scan_i32_pair(ctx, p->aprod_off.as<int>(), p->lprod_off.as<int>(), (size_t)nA, ctx->d_scalars + 3, ctx->d_scalars));
     int64_t P = 0, Pall = 0;
     {
@@ -1592,7 +1692,8 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
         int grid = counts[BIN] < (MAXGRID) ? counts[BIN] : (MAXGRID);                                                                \
         PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<" #CAP ">", (s1_rowsort_kernel<KeyT, CAP, QB, THREADS, RCAP>), grid, THREADS,             \
                          rl + (size_t)(BIN) * mt, counts[BIN], A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, A->tile_colidx.as<int>(), \
-                         p->aprod_off.as<int>(), p->lprod_off.as<int>(), B->tile_rowptr.as<int>(), B->tile_colidx.as<int>(),         \
+                         p->aprod_off.as<int>(), p->row_n.as<int>(), p->row_lbase.as<int>(), B->tile_rowptr.as<int>(),              \
+                         B->tile_colidx.as<int>(),                                                                                     \
                          A->tile_occ.as<uint32_t>(), B->tile_occ.as<uint32_t>(), prune, p->pairs_a.as<int>(), p->pairs_b.as<int>(),   \
                          p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->block_info.as<int2>(), p->c_tile_rowptr.as<int>(),     \
                          key_bits);                                                                                                    \
@@ -1672,32 +1773,42 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     PEM_TRY(p->bin_count.reserve(sizeof(int) * 8));
     PEM_TRY(p->xl_base.reserve(sizeof(int) * ((size_t)mt + 4)));
     PEM_TRY(p->pairs_offset.reserve(sizeof(int) * 4));
-    // one launch clears the status flags, the bin counters, the pass scalars (P live, T_C, C_nnz, P all) and
-    // pairs_offset[0]; the per-row tile counts in c_tile_rowptr are zeroed by the row classification below
-    PEM_LAUNCH(ctx, s1_reset_kernel, 1, 64, ctx->d_flags, p->bin_count.as<int>(), reinterpret_cast<long long *>(ctx->d_scalars),
-               p->pairs_offset.as<int>(), p->c_tile_rowptr.as<int>(), mt);
-    // product offsets per A tile: all products (expansion / sort capacity) and live products (output positions)
+    // one launch clears the status flags, the bin counters, the pass scalars (P live, T_C, C_nnz, P all), pairs_offset[0]
+    // and the per-row product totals; the per-row tile counts in c_tile_rowptr are zeroed by the row classification below
+    PEM_TRY(p->row_n.reserve(sizeof(int) * ((size_t)mt + 4)));
+    PEM_TRY(p->row_lbase.reserve(sizeof(int) * ((size_t)mt + 4)));
+    PEM_LAUNCH(ctx, s1_reset_kernel, grid_for((size_t)mt + 1, 256), 256, ctx->d_flags, p->bin_count.as<int>(),
+               reinterpret_cast<long long *>(ctx->d_scalars), p->pairs_offset.as<int>(), p->c_tile_rowptr.as<int>(), mt, p->row_n.as<int>(),
+               p->row_lbase.as<int>());
+    // products per A tile (all: expansion; live: what is sorted and stored) and their totals per tile row.  The only scan
+    // left is the one over the ROWS' live totals (row r's pairs, and its C tile slots, start at row_lbase[r]); offsets inside
+    // a row are rebuilt in LDS by the row's workgroup, and the grand total of all products is only ever a 64-bit scalar --
+    // so a product whose tile-level products exceed 2^31 (cage15 on one GPU: 2.8 G) is fine as long as the LIVE pairs,
+    // which the reference's int arrays index, do not.
     const int prune = p->opt_prune;
     PEM_TRY(p->aprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
     PEM_TRY(p->lprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
     if (nA > 0)
         PEM_LAUNCH(ctx, s1_aprod_kernel, grid_for((size_t)nA * 8, 256), 256, A->tile_colidx.as<int>(), A->tile_occ.as<uint32_t>(), p->a_lo, nA,
-                   B->tile_rowptr.as<int>(), B->tile_occ.as<uint32_t>(), prune, p->aprod_off.as<int>(), p->lprod_off.as<int>());
-    PEM_TRY(exclusive_scan_i32_pair(ctx, p->aprod_off.as<int>(), p->lprod_off.as<int>(), (size_t)nA, ctx->d_scalars + 3, ctx->d_scalars));
+                   B->tile_rowptr.as<int>(), B->tile_occ.as<uint32_t>(), prune, p->aprod_off.as<int>(), p->lprod_off.as<int>(),
+                   A->tile_keys.as<long long>(), p->tr_lo, p->row_n.as<int>(), p->row_lbase.as<int>());
+    PEM_TRY(exclusive_scan_i32(ctx, p->row_lbase.as<int>(), p->row_lbase.as<int>(), (size_t)mt, ctx->d_scalars));
     // per-row tile counts are accumulated in c_tile_rowptr and scanned in place afterwards
     if (mt > 0)
-        PEM_LAUNCH(ctx, s1_rowclass_kernel, grid_for((size_t)mt, 256), 256, A->tile_rowptr.as<int>(), p->tr_lo, mt, p->a_lo,
-                   p->aprod_off.as<int>(), p->lprod_off.as<int>(), cap3, qcap, xlcap, p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(),
-                   p->c_tile_rowptr.as<int>());
+        PEM_LAUNCH(ctx, s1_rowclass_kernel, grid_for((size_t)mt, 256), 256, A->tile_rowptr.as<int>(), p->tr_lo, mt, p->row_n.as<int>(),
+                   p->row_lbase.as<int>(), cap3, qcap, xlcap, p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(),
+                   p->c_tile_rowptr.as<int>(), reinterpret_cast<long long *>(ctx->d_scalars));
     // one read-back: P, the bin populations and the product total of the oversized rows
     int64_t P = 0, Pall = 0;
     int counts[4];
     size_t n_xl;
+    int nrows_xl = 0;
     if (p->warm_pass) {
         P = p->w_P;
         Pall = p->w_Pall;
         for (int b = 0; b < 4; ++b) counts[b] = p->w_counts[b];
         n_xl = (size_t)p->w_nxl;
+        nrows_xl = p->w_nrows_xl;
     } else {
         int *hb = reinterpret_cast<int *>(ctx->h_scalars + 32);
         PEM_HIP(hipMemcpyAsync(hb, p->bin_count.p, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
@@ -1707,13 +1818,14 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         Pall = sc[3];
         for (int b = 0; b < 4; ++b) counts[b] = p->w_counts[b] = hb[b];
         n_xl = (size_t)hb[5];
+        nrows_xl = p->w_nrows_xl = hb[4];
         p->w_nxl = (int64_t)n_xl;
         p->w_P = P;
         p->w_Pall = Pall;
     }
     p->npairs_all = Pall;
-    if (P > 0x7FFFFFFFll || Pall > 0x7FFFFFFFll) {
-        set_error("step 1: %lld tile pairs exceed the int32 range of the reference's pair arrays", (long long)P);
+    if (P > 0x7FFFFFFFll) {
+        set_error("step 1: %lld live tile pairs exceed the int32 range of the reference's pair arrays", (long long)P);
         return PEM_E_OVERFLOW;
     }
     p->npairs = P;
@@ -1737,8 +1849,11 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
             PEM_TRY(p->sv0.reserve(sizeof(uint32_t) * n_xl));
             PEM_TRY(p->sv1.reserve(sizeof(uint32_t) * n_xl));
             PEM_TRY(p->xl_rowstart.reserve(sizeof(int) * ((size_t)mt + 4)));
+            PEM_TRY(p->xl_lrel.reserve(sizeof(int) * ((size_t)nA + 4)));
+            PEM_LAUNCH(ctx, s1_xl_rel_kernel, (unsigned)(nrows_xl > 0 ? nrows_xl : 1), 256, p->row_list.as<int>() + (size_t)4 * mt, nrows_xl,
+                       A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->lprod_off.as<int>(), p->xl_lrel.as<int>());
             PEM_LAUNCH(ctx, s1_xl_expand_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_keys.as<long long>(), A->tile_rowptr.as<int>(),
-                       A->tile_occ.as<uint32_t>(), p->a_lo, nA, p->tr_lo, p->lprod_off.as<int>(), p->xl_base.as<int>(), B->tile_rowptr.as<int>(),
+                       A->tile_occ.as<uint32_t>(), p->a_lo, nA, p->tr_lo, p->xl_lrel.as<int>(), p->xl_base.as<int>(), B->tile_rowptr.as<int>(),
                        B->tile_colidx.as<int>(), B->tile_occ.as<uint32_t>(), prune, bits_tc, p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(),
                        p->prod_a.as<int>(), p->prod_b.as<int>());
             uint64_t *keys = nullptr;
@@ -1751,7 +1866,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
             PEM_TRY(exclusive_scan_i32(ctx, head.as<int>(), head.as<int>(), n_xl, nullptr));
             PEM_LAUNCH(ctx, s1_xl_rowstart_kernel, grid_for(n_xl, 256), 256, keys, n_xl, bits_tc, p->xl_rowstart.as<int>());
             PEM_LAUNCH(ctx, s1_xl_emit_kernel, grid_for(n_xl, 256), 256, keys, perm, head.as<int>(), n_xl, bits_tc, p->xl_rowstart.as<int>(),
-                       A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->lprod_off.as<int>(), p->prod_a.as<int>(), p->prod_b.as<int>(),
+                       p->row_lbase.as<int>(), p->prod_a.as<int>(), p->prod_b.as<int>(),
                        p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(),
                        p->block_info.as<int2>(), p->c_tile_rowptr.as<int>());
         }
@@ -1779,15 +1894,14 @@ static pem_status ensure_compact(pem_ctx *ctx, const pem_cplan *cp)
 {
     pem_cplan *p = const_cast<pem_cplan *>(cp);
     if (p->compact_valid || !p->pairs_ready || p->state < 1) return PEM_OK;
-    const pem_tiled *A = p->A;
     const int mt = p->tr_hi - p->tr_lo;
     const size_t ntc = (size_t)p->ntiles_c;
     PEM_HIP(hipSetDevice(ctx->device));
     PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
     PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
     if (mt > 0)
-        PEM_LAUNCH(ctx, s1_compact_kernel, (unsigned)mt, 256, p->c_tile_rowptr.as<int>(), mt, (long long)ntc, p->tr_lo, A->tile_rowptr.as<int>(),
-                   p->a_lo, p->lprod_off.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), (int)p->npairs,
+        PEM_LAUNCH(ctx, s1_compact_kernel, (unsigned)mt, 256, p->c_tile_rowptr.as<int>(), mt, (long long)ntc, p->row_lbase.as<int>(),
+                   p->scratch_col.as<int>(), p->scratch_off.as<int>(), (int)p->npairs,
                    p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>());
     p->compact_valid = true;
     return PEM_OK;

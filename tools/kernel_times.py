@@ -1,4 +1,5 @@
-"""per-kernel device times of one product: python tools/kernel_times.py [workload] [scale] (env switches apply)"""
+"""per-kernel device times of one product (or of one rank's row block of an N-way split):
+    python tools/kernel_times.py [workload] [scale] [nparts] [part]   (env switches apply)"""
 import importlib
 import os
 import sys
@@ -13,7 +14,10 @@ scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 rows, cols, I, J, V = standins.make(name, scale)
 ctx = pkg.Context(0)
 A = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V)
-plan = pkg.CPlan(ctx, A, A)
+nparts = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+part = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+bounds = pkg.split_tile_rows(ctx, A, A, nparts)
+plan = pkg.CPlan(ctx, A, A, int(bounds[part]), int(bounds[part + 1]))
 for _ in range(3):
     try:
         plan.spgemm()
