@@ -100,6 +100,7 @@ struct pem_ctx {
     int *d_flags = nullptr;            // NUM_FLAGS ints
     // shared temporaries (grow-only, reused by every call on this context)
     pem::DevBuf scan_bsum;             // block sums of the device scan
+    pem::DevBuf scan_state;            // mid-size scan: one published total per block + completion counter
     pem::DevBuf sort_hist;             // radix-sort histograms
     bool graph_replay = false;         // pem_set_graph_replay: repeat passes of pem_spgemm are replayed as one hipGraph
     bool capturing = false;            // a warm pass is being captured into a hipGraph: no timing events, no syncs

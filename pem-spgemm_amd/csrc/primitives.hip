@@ -226,7 +226,6 @@ __global__ void scan_empty_kernel(int *out, long long *total64)
 }
 
 // short arrays (row counts of a slice, histogram tails): one 1024-thread block does the whole scan in one launch
-constexpr size_t SCAN_SMALL = 131072;
 __global__ void __launch_bounds__(1024) scan_small_kernel(const int *in, int *out, size_t n, long long *__restrict__ total64,
                                                           int *__restrict__ flags)
 {
@@ -280,6 +279,93 @@ __global__ void __launch_bounds__(1024) scan_small_kernel(const int *in, int *ou
     }
 }
 
+// mid-size arrays (tile-row counts of a plan, 256-tile group counts): ONE launch of up to SCAN_MID_BLOCKS blocks.  Every
+// block scans its 2048 items, publishes its total, and sums the totals of all earlier blocks -- at most 127 words, two per
+// lane of one wave, read in one round trip.  So few blocks are all resident at once, so the wait is for blocks that are
+// already running; should one not have published within the poll budget (it never has), the block adds up the input in
+// front of it itself -- slow, never wrong, never a hang.  The last block to finish clears the words for the next scan.
+// A single 1024-thread block took 17 us for 62 k items and 35 us for 75 k (8192 items per trip, two barriers each).
+constexpr int SCAN_MID_ITEMS = 2048, SCAN_MID_BLOCKS = 128;
+constexpr unsigned long long SCAN_MID_VALID = 1ull << 63;
+
+__global__ void __launch_bounds__(256) scan_mid_kernel(const int *in, int *out, size_t n, unsigned long long *state, int *done,
+                                                       long long *__restrict__ total64, int *__restrict__ flags)
+{
+    __shared__ int wsum[4];
+    __shared__ long long s_excl;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x, nblk = gridDim.x;
+    const size_t i0 = (size_t)blk * SCAN_MID_ITEMS + (size_t)tid * 8;
+    int v[8];
+    if (i0 + 8 <= n) {
+        const int4 q0 = *reinterpret_cast<const int4 *>(in + i0), q1 = *reinterpret_cast<const int4 *>(in + i0 + 4);
+        v[0] = q0.x; v[1] = q0.y; v[2] = q0.z; v[3] = q0.w;
+        v[4] = q1.x; v[5] = q1.y; v[6] = q1.z; v[7] = q1.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (i0 + k < n) ? in[i0 + k] : 0;
+    }
+    int tsum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tsum += v[k];
+    const int inc = wave_inclusive_scan(tsum);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0, btotal = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (w < wave) woff += wsum[w];
+        btotal += wsum[w];
+    }
+    if (wave == 0) {
+        if (lane == 0) __hip_atomic_store(&state[blk], SCAN_MID_VALID | (unsigned long long)(unsigned)btotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long excl = 0;
+        bool ok = false;
+        for (int polls = 0; polls < (1 << 16) && !ok; ++polls) {
+            const unsigned long long a = lane < blk ? __hip_atomic_load(&state[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SCAN_MID_VALID;
+            const unsigned long long b = 64 + lane < blk ? __hip_atomic_load(&state[64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SCAN_MID_VALID;
+            if (__ballot(!(a & SCAN_MID_VALID) || !(b & SCAN_MID_VALID)) == 0) {
+                excl = wave_reduce_sum((long long)(a & 0xFFFFFFFFull) + (long long)(b & 0xFFFFFFFFull));
+                ok = true;
+            } else {
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (!ok) {   // an earlier block is not running (never observed): sum the input in front of this block
+            long long sacc = 0;
+            for (size_t i = lane; i < (size_t)blk * SCAN_MID_ITEMS; i += 64) sacc += in[i];
+            excl = wave_reduce_sum(sacc);
+        }
+        if (lane == 0) s_excl = excl;
+    }
+    __syncthreads();
+    const long long carry = s_excl;
+    int o[8];
+    o[0] = (int)carry + woff + inc - tsum;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) o[k] = o[k - 1] + v[k - 1];
+    if (i0 + 8 <= n) {
+        *reinterpret_cast<int4 *>(out + i0) = make_int4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<int4 *>(out + i0 + 4) = make_int4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + k < n) out[i0 + k] = o[k];
+    }
+    if (tid == 0) {
+        if (blk == nblk - 1) {
+            const long long total = carry + btotal;
+            out[n] = (int)total;
+            if (total64) *total64 = total;
+            if (total > 0x7FFFFFFFLL) flags[FLAG_OVERFLOW] = 1;
+        }
+        // the last block to get here has seen every other block read what it needed: clear the words for the next scan
+        if (atomicAdd(done, 1) == nblk - 1) {
+            for (int b = 0; b < nblk; ++b) __hip_atomic_store(&state[b], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 pem_status exclusive_scan_i32(pem_ctx *ctx, const int *in, int *out, size_t n, int64_t *d_total64)
 {
     if (n == 0) {
@@ -290,8 +376,18 @@ pem_status exclusive_scan_i32(pem_ctx *ctx, const int *in, int *out, size_t n, i
         set_error("exclusive_scan_i32: unaligned pointer");
         return PEM_E_INVALID;
     }
-    if (n <= SCAN_SMALL) {
+    if (n <= 8192) {
         PEM_LAUNCH(ctx, scan_small_kernel, 1, 1024, in, out, n, reinterpret_cast<long long *>(d_total64), ctx->d_flags);
+        return PEM_OK;
+    }
+    if (n <= (size_t)SCAN_MID_ITEMS * SCAN_MID_BLOCKS) {
+        if (!ctx->scan_state.p) {   // look-back words + completion counter, zero between scans
+            PEM_TRY(ctx->scan_state.reserve(sizeof(unsigned long long) * (SCAN_MID_BLOCKS + 2)));
+            PEM_HIP(hipMemsetAsync(ctx->scan_state.p, 0, sizeof(unsigned long long) * (SCAN_MID_BLOCKS + 2), ctx->stream));
+        }
+        unsigned long long *state = ctx->scan_state.as<unsigned long long>();
+        PEM_LAUNCH(ctx, scan_mid_kernel, (unsigned)((n + SCAN_MID_ITEMS - 1) / SCAN_MID_ITEMS), 256, in, out, n, state,
+                   reinterpret_cast<int *>(state + SCAN_MID_BLOCKS), reinterpret_cast<long long *>(d_total64), ctx->d_flags);
         return PEM_OK;
     }
     int nblk = (int)((n + SCAN_BLOCK_ITEMS - 1) / SCAN_BLOCK_ITEMS);
@@ -414,7 +510,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan2_apply_kernel(ScanPair sp, 
 
 pem_status exclusive_scan_i32_pair(pem_ctx *ctx, int *a, int *b, size_t n, int64_t *d_total_a, int64_t *d_total_b)
 {
-    if (n <= SCAN_SMALL) {   // short: two single-launch scans
+    if (n <= (size_t)SCAN_MID_ITEMS * SCAN_MID_BLOCKS) {   // short: two single-launch scans
         PEM_TRY(exclusive_scan_i32(ctx, a, a, n, d_total_a));
         return exclusive_scan_i32(ctx, b, b, n, d_total_b);
     }
