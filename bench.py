@@ -45,15 +45,13 @@ def kernel_alg_bytes(name, d):
         "s2_cmask_kernel": 8 * P + 32 * TA + 32 * TB + 36 * TC,
         "s2_crowcol_kernel": 36 * TC + 16 * TC + NZ,
         "s3_accumulate_kernel": 8 * P + 8 * TC + NZ + (vb * nA + 52 * TA) + (vb * nB + 84 * TB) + vb * NZ,
-        # fused step 2: scratch (8 B/slot) + pair ids in, masks of both operands, 44 B per C tile + the (r<<4|c) bytes out
-        "s2_tiles_kernel": 16 * P + 32 * TA + 32 * TB + 44 * TC,
-        "s2_tiles_kernel<rc>": 16 * P + 32 * TA + 32 * TB + 44 * TC + NZ,
-        "s2_crowcol_wide_kernel": 36 * TC + NZ,
+        # step 2: scratch (8 B/slot) + pair ids in, masks of both operands, 40 B per C tile out; then masks in, offsets + (r<<4|c) out
+        "s2_tiles_kernel": 16 * P + 32 * TA + 32 * TB + 40 * TC,
+        "s2_entries_kernel": 36 * TC + NZ,
         "s3_accumulate_wide_kernel": 8 * P + 8 * TC + NZ + (vb * nA + 68 * TA) + (vb * nB + 100 * TB) + vb * NZ,
     }
-    for suffix in ("<double>", "<float>"):          # value-typed kernels carry their template argument in the name
-        if name.endswith(suffix):
-            name = name[:-len(suffix)]
+    if name.startswith("s3_accumulate"):            # value-typed kernels carry their template arguments in the name
+        name = name.split("<")[0]
     return table.get(name)
 
 

@@ -1253,7 +1253,7 @@ __global__ void __launch_bounds__(256) s2_crowptr_kernel(const uint32_t *__restr
 // the two operand values.  Pairs ascend in k-tile, bits ascend, one fma per product: the same
 // chain as the oracle.
 constexpr int S3_EPW = S3_CHUNK;   // C entries per wave
-template <typename VT>
+template <typename VT, bool DEEP>
 __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b, long long ntc,
     const int *__restrict__ c_tile_nnz_ptr, long long nnz_c, const uint8_t *__restrict__ c_rowcolidx, VT *__restrict__ c_vals,
@@ -1296,7 +1296,41 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
         const unsigned rc = c_rowcolidx[e];
         const int r = rc >> 4, c = rc & 15;
         VT acc = VT(0);
-        for (int p = p0; p < p1; ++p) {
+        int p = p0;
+        // DEEP (plans averaging two or more pairs per C tile: 3.1 on cage15-class inputs, 30+ where a band multiplies
+        // itself): four pairs per trip, their eight record gathers in flight together instead of four dependent round
+        // trips; the products are still added pair by pair in ascending order.  cage15 slice: 17.3 -> 14.7 ms.  Not for
+        // everyone: webbase-1M's tiles hold 1.08 pairs and the extra code costs it 10 % (3 % when guarded by a wave vote,
+        // which in turn loses cage15's gain).
+        for (; DEEP && p + 4 <= p1; p += 4) {
+            int a4[4], b4[4];
+            unsigned aw4[4], bw4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a4[k] = pairs_a[p + k];
+                b4[k] = pairs_b[p + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                aw4[k] = a_rec[16 * (size_t)a4[k] + r];
+                bw4[k] = b_rec_t[16 * (size_t)b4[k] + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned am = aw4[k] & 0xFFFFu, bm = bw4[k] & 0xFFFFu;
+                unsigned m = am & bm;
+                if (!m) continue;
+                const VT *av = a_vals + a_nnz_ptr[a4[k]] + (aw4[k] >> 16);
+                const VT *bv = b_vals_t + b_nnz_ptr[b4[k]] + (bw4[k] >> 16);
+                while (m) {
+                    const int kk = __builtin_ctz(m);
+                    m &= m - 1;
+                    const unsigned below = (1u << kk) - 1u;
+                    acc = pem_fma(av[__popc(am & below)], bv[__popc(bm & below)], acc);
+                }
+            }
+        }
+        for (; p < p1; ++p) {
             const int a = pairs_a[p], b = pairs_b[p];
             const unsigned aw = a_rec[16 * (size_t)a + r];
             const unsigned am = aw & 0xFFFFu;
@@ -2030,25 +2064,31 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
     if (!ctx->chain_events) PEM_HIP(hipEventRecord(ctx->ev[4], st));
     const bool wide = p->wide;   // step 2's choice: the entry-per-lane kernel needs the chunk index the fused path wrote
     const bool f32 = A->value_bytes == 4;
+#define PEM_S3_WIDE(VT, DEEP, NAME)                                                                                                            \
+    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, DEEP>), grid_for(((size_t)p->nnz_c + S3_EPW - 1) / S3_EPW * 64, 256), 256,     \
+                     p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),       \
+                     (long long)p->nnz_c, p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),       \
+                     A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                  \
+                     p->s3_chunk_tile.as<int>())
 #define PEM_S3_LAUNCH(VT)                                                                                                                      \
     do {                                                                                                                                       \
-        if (wide)                                                                                                                              \
-            PEM_LAUNCH(ctx, s3_accumulate_wide_kernel<VT>, grid_for(((size_t)p->nnz_c + S3_EPW - 1) / S3_EPW * 64, 256), 256,                  \
-                       p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),     \
-                       (long long)p->nnz_c, p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),     \
-                       A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                \
-                       p->s3_chunk_tile.as<int>());                                                                                            \
+        if (wide && deep)                                                                                                                      \
+            PEM_S3_WIDE(VT, true, "s3_accumulate_wide_kernel<" #VT ",deep>");                                                                  \
+        else if (wide)                                                                                                                         \
+            PEM_S3_WIDE(VT, false, "s3_accumulate_wide_kernel<" #VT ">");                                                                      \
         else                                                                                                                                   \
             PEM_LAUNCH(ctx, s3_accumulate_kernel<VT>, grid_for(ntc * 16, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(),           \
                        p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(),    \
                        A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(), A->masks.as<uint16_t>(), A->rowptr.as<uint8_t>(),                          \
                        B->tile_nnz_ptr.as<int>(), B->vals.as<VT>(), B->masks.as<uint16_t>(), B->rowptr.as<uint8_t>(), B->masks_t.as<uint16_t>()); \
     } while (0)
+    const bool deep = p->npairs >= 2 * p->ntiles_c;   // two or more pairs per C tile on average (see the kernel)
     if (ntc > 0 && f32)
         PEM_S3_LAUNCH(float);
     else if (ntc > 0)
         PEM_S3_LAUNCH(double);
 #undef PEM_S3_LAUNCH
+#undef PEM_S3_WIDE
     if (!ctx->capturing) PEM_HIP(hipEventRecord(ctx->ev[5], st));
     p->state = 3;
     return PEM_OK;
