@@ -1,0 +1,217 @@
+// mgpu.hip -- libpemmgpu.so: one process, one pem_ctx per GPU, and the path's one exchange step -- the gather of the
+// per-rank CSR slices of C to a root device over RCCL (include/pem_mgpu.h).  The reference is single-GPU,
+// so nothing of it is replaced here.  Host code only: no kernels; device work goes through the C ABI of
+// libpemspgemm_hip.so (export) and RCCL (transfer).  On the xGMI mesh every slice has its own direct link into the root.
+#include "pem_internal.h"
+#include "../../include/pem_mgpu.h"
+#include <chrono>
+#include <rccl/rccl.h>
+
+using namespace pem;
+
+struct pem_mgpu {
+    int n = 0;
+    std::vector<int> dev;
+    std::vector<pem_ctx *> ctx;
+    std::vector<ncclComm_t> comm;
+    std::vector<hipStream_t> stream;            // the transfers' streams, one per device
+    std::vector<DevBuf> s_rp, s_ci, s_v;        // per rank: the slice as CSR on its own device
+    DevBuf r_ci, r_v;                           // root: the assembled column indices / values
+};
+
+#define PEM_NCCL(expr)                                                                             \
+    do {                                                                                           \
+        ncclResult_t _r = (expr);                                                                  \
+        if (_r != ncclSuccess) {                                                                   \
+            pem::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, ncclGetErrorString(_r));  \
+            return PEM_E_HIP;                                                                      \
+        }                                                                                          \
+    } while (0)
+
+extern "C" pem_status pem_mgpu_create(int ndev, const int *devices, pem_mgpu **out)
+{
+    if (!out || ndev < 1 || !devices) return PEM_E_INVALID;
+    *out = nullptr;
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have < 1) {
+        set_error("pem_mgpu_create: no usable GPU (the product path has no CPU fallback)");
+        return PEM_E_NODEVICE;
+    }
+    for (int g = 0; g < ndev; ++g) {
+        if (devices[g] < 0 || devices[g] >= have) {
+            set_error("pem_mgpu_create: device %d requested, %d visible", devices[g], have);
+            return PEM_E_INVALID;
+        }
+        for (int h = 0; h < g; ++h)
+            if (devices[h] == devices[g]) {
+                set_error("pem_mgpu_create: device %d listed twice (one rank per GPU)", devices[g]);
+                return PEM_E_INVALID;
+            }
+    }
+    pem_mgpu *m = new pem_mgpu();
+    m->n = ndev;
+    m->dev.assign(devices, devices + ndev);
+    m->ctx.assign((size_t)ndev, nullptr);
+    m->comm.assign((size_t)ndev, nullptr);
+    m->stream.assign((size_t)ndev, nullptr);
+    m->s_rp = std::vector<DevBuf>((size_t)ndev);
+    m->s_ci = std::vector<DevBuf>((size_t)ndev);
+    m->s_v = std::vector<DevBuf>((size_t)ndev);
+    auto fail = [&](pem_status s) {
+        pem_mgpu_destroy(m);
+        return s;
+    };
+    for (int g = 0; g < ndev; ++g) {
+        pem_status s = pem_ctx_create(devices[g], &m->ctx[(size_t)g]);
+        if (s != PEM_OK) return fail(s);
+        if (hipSetDevice(devices[g]) != hipSuccess || hipStreamCreateWithFlags(&m->stream[(size_t)g], hipStreamNonBlocking) != hipSuccess) {
+            set_error("pem_mgpu_create: stream on device %d", devices[g]);
+            return fail(PEM_E_HIP);
+        }
+    }
+    ncclResult_t r = ncclCommInitAll(m->comm.data(), ndev, devices);
+    if (r != ncclSuccess) {
+        set_error("ncclCommInitAll over %d devices: %s", ndev, ncclGetErrorString(r));
+        for (auto &c : m->comm) c = nullptr;
+        return fail(PEM_E_HIP);
+    }
+    *out = m;
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_mgpu_destroy(pem_mgpu *m)
+{
+    if (!m) return PEM_OK;
+    for (int g = 0; g < m->n; ++g) {
+        (void)hipSetDevice(m->dev[(size_t)g]);
+        if (m->stream[(size_t)g]) (void)hipStreamSynchronize(m->stream[(size_t)g]);
+        if (m->comm[(size_t)g]) (void)ncclCommDestroy(m->comm[(size_t)g]);
+        m->s_rp[(size_t)g].release();
+        m->s_ci[(size_t)g].release();
+        m->s_v[(size_t)g].release();
+        if (m->stream[(size_t)g]) (void)hipStreamDestroy(m->stream[(size_t)g]);
+    }
+    m->r_ci.release();
+    m->r_v.release();
+    for (int g = 0; g < m->n; ++g)
+        if (m->ctx[(size_t)g]) (void)pem_ctx_destroy(m->ctx[(size_t)g]);
+    delete m;
+    return PEM_OK;
+}
+
+extern "C" int pem_mgpu_size(const pem_mgpu *m) { return m ? m->n : 0; }
+extern "C" pem_ctx *pem_mgpu_ctx(pem_mgpu *m, int rank) { return (m && rank >= 0 && rank < m->n) ? m->ctx[(size_t)rank] : nullptr; }
+
+extern "C" void pem_mgpu_slice_offsets(int n, const int64_t *nrows, const int64_t *nnz, int64_t *row_off, int64_t *nnz_off)
+{
+    row_off[0] = nnz_off[0] = 0;
+    for (int g = 0; g < n; ++g) {
+        row_off[g + 1] = row_off[g] + nrows[g];
+        nnz_off[g + 1] = nnz_off[g] + nnz[g];
+    }
+}
+
+extern "C" void pem_mgpu_rebase_rowptr(int n, const int64_t *nrows, const int32_t *const *slice_rowptr, const int64_t *row_off,
+                                       const int64_t *nnz_off, int32_t *out)
+{
+    for (int g = 0; g < n; ++g)
+        for (int64_t r = 0; r < nrows[g]; ++r) out[row_off[g] + r] = (int32_t)((int64_t)slice_rowptr[g][r] + nnz_off[g]);
+    out[row_off[n]] = (int32_t)nnz_off[n];
+}
+
+extern "C" pem_status pem_mgpu_gather_csr(pem_mgpu *m, pem_cplan *const *plans, int root, int64_t *nrows_out, int64_t *nnz_out,
+                                          int32_t *rowptr, int32_t *colidx, double *vals, double *gather_ms)
+{
+    if (!m || !plans || root < 0 || root >= m->n) return PEM_E_INVALID;
+    const int n = m->n;
+    std::vector<int64_t> nrows((size_t)n), nnz((size_t)n), row_off((size_t)n + 1), nnz_off((size_t)n + 1);
+    for (int g = 0; g < n; ++g) {
+        if (!plans[g]) return PEM_E_INVALID;
+        pem_cplan_info ci;
+        PEM_TRY(pem_cplan_get_info(plans[g], &ci));
+        if (g > 0) {
+            pem_cplan_info prev;
+            PEM_TRY(pem_cplan_get_info(plans[g - 1], &prev));
+            if (prev.tile_row_end != ci.tile_row_begin) {
+                set_error("pem_mgpu_gather_csr: plan %d covers tile rows [%d, %d), plan %d ends at %d -- row blocks must abut in rank order", g,
+                          ci.tile_row_begin, ci.tile_row_end, g - 1, prev.tile_row_end);
+                return PEM_E_INVALID;
+            }
+        }
+        nrows[(size_t)g] = ci.row_end - ci.row_begin;
+        nnz[(size_t)g] = ci.nnz_c;
+    }
+    pem_mgpu_slice_offsets(n, nrows.data(), nnz.data(), row_off.data(), nnz_off.data());
+    if (nnz_off[(size_t)n] > 0x7FFFFFFFll) {
+        set_error("pem_mgpu_gather_csr: the assembled C has %lld nonzeros, beyond int32 row pointers", (long long)nnz_off[(size_t)n]);
+        return PEM_E_OVERFLOW;
+    }
+    if (nrows_out) *nrows_out = row_off[(size_t)n];
+    if (nnz_out) *nnz_out = nnz_off[(size_t)n];
+    if (!rowptr) return PEM_OK;   // size query
+    const size_t total = (size_t)nnz_off[(size_t)n];
+    if (total && (!colidx || !vals)) return PEM_E_INVALID;
+
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    PEM_HIP(hipSetDevice(m->dev[(size_t)root]));
+    PEM_TRY(m->r_ci.reserve(sizeof(int32_t) * (total + 4)));
+    PEM_TRY(m->r_v.reserve(sizeof(double) * (total + 1)));
+    // every rank: tiled C slice -> CSR on its own device (the root writes its slice straight into the assembled arrays)
+    for (int g = 0; g < n; ++g) {
+        PEM_HIP(hipSetDevice(m->dev[(size_t)g]));
+        PEM_TRY(m->s_rp[(size_t)g].reserve(sizeof(int32_t) * ((size_t)nrows[(size_t)g] + 4)));
+        int32_t *ci = nullptr;
+        double *v = nullptr;
+        if (g == root) {
+            ci = m->r_ci.as<int32_t>() + nnz_off[(size_t)g];
+            v = m->r_v.as<double>() + nnz_off[(size_t)g];
+        } else {
+            PEM_TRY(m->s_ci[(size_t)g].reserve(sizeof(int32_t) * ((size_t)nnz[(size_t)g] + 4)));
+            PEM_TRY(m->s_v[(size_t)g].reserve(sizeof(double) * ((size_t)nnz[(size_t)g] + 1)));
+            ci = m->s_ci[(size_t)g].as<int32_t>();
+            v = m->s_v[(size_t)g].as<double>();
+        }
+        PEM_TRY(pem_c_export_csr_device(m->ctx[(size_t)g], plans[g], m->s_rp[(size_t)g].as<int32_t>(), ci, v));
+    }
+    for (int g = 0; g < n; ++g) PEM_TRY(pem_ctx_synchronize(m->ctx[(size_t)g]));   // the exports ran on the contexts' streams
+    // one RCCL group: slice g -> its place in the root's arrays
+    if (n > 1) {
+        PEM_NCCL(ncclGroupStart());
+        for (int g = 0; g < n; ++g) {
+            if (g == root || nnz[(size_t)g] == 0) continue;
+            PEM_HIP(hipSetDevice(m->dev[(size_t)g]));
+            PEM_NCCL(ncclSend(m->s_ci[(size_t)g].p, (size_t)nnz[(size_t)g], ncclInt32, root, m->comm[(size_t)g], m->stream[(size_t)g]));
+            PEM_NCCL(ncclSend(m->s_v[(size_t)g].p, (size_t)nnz[(size_t)g], ncclFloat64, root, m->comm[(size_t)g], m->stream[(size_t)g]));
+        }
+        PEM_HIP(hipSetDevice(m->dev[(size_t)root]));
+        for (int g = 0; g < n; ++g) {
+            if (g == root || nnz[(size_t)g] == 0) continue;
+            PEM_NCCL(ncclRecv(m->r_ci.as<int32_t>() + nnz_off[(size_t)g], (size_t)nnz[(size_t)g], ncclInt32, g, m->comm[(size_t)root],
+                              m->stream[(size_t)root]));
+            PEM_NCCL(ncclRecv(m->r_v.as<double>() + nnz_off[(size_t)g], (size_t)nnz[(size_t)g], ncclFloat64, g, m->comm[(size_t)root],
+                              m->stream[(size_t)root]));
+        }
+        PEM_NCCL(ncclGroupEnd());
+        for (int g = 0; g < n; ++g) {
+            PEM_HIP(hipSetDevice(m->dev[(size_t)g]));
+            PEM_HIP(hipStreamSynchronize(m->stream[(size_t)g]));
+        }
+    }
+    if (gather_ms) *gather_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
+    // row pointers: a few MB, copied out by their owners and rebased on the host
+    std::vector<std::vector<int32_t>> rp((size_t)n);
+    std::vector<const int32_t *> rpp((size_t)n);
+    for (int g = 0; g < n; ++g) {
+        rp[(size_t)g].resize((size_t)nrows[(size_t)g] + 1);
+        PEM_HIP(hipSetDevice(m->dev[(size_t)g]));
+        PEM_HIP(hipMemcpy(rp[(size_t)g].data(), m->s_rp[(size_t)g].p, sizeof(int32_t) * ((size_t)nrows[(size_t)g] + 1), hipMemcpyDeviceToHost));
+        rpp[(size_t)g] = rp[(size_t)g].data();
+    }
+    pem_mgpu_rebase_rowptr(n, nrows.data(), rpp.data(), row_off.data(), nnz_off.data(), rowptr);
+    if (total) {
+        PEM_HIP(hipSetDevice(m->dev[(size_t)root]));
+        PEM_HIP(hipMemcpy(colidx, m->r_ci.p, sizeof(int32_t) * total, hipMemcpyDeviceToHost));
+        PEM_HIP(hipMemcpy(vals, m->r_v.p, sizeof(double) * total, hipMemcpyDeviceToHost));
+    }
+    return PEM_OK;
+}

@@ -5,6 +5,7 @@
 // per-kernel timing.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -33,9 +34,9 @@ void set_error(const char *fmt, ...);
 
 // Grow-only device buffer.  Contents are NOT preserved across a growth.
 // bumped whenever any device buffer is (re)allocated or freed: a captured pass (hipGraph) bakes buffer addresses in
-inline unsigned long long &alloc_generation()
+inline std::atomic<unsigned long long> &alloc_generation()   // atomic: one host thread per device in multi-GPU runs
 {
-    static unsigned long long gen = 0;
+    static std::atomic<unsigned long long> gen{0};
     return gen;
 }
 

@@ -7,6 +7,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpemhost.so")
+MGPU_LIB_PATH = os.path.join(_HERE, "libpemmgpu.so")   # include/pem_mgpu.h: contexts of one process over several GPUs + RCCL gather
 CLI_PATH = os.path.join(_HERE, "pemspgemm")
 
 HOST_SYMBOLS = ["pem_mm_read", "pem_coo_free", "pem_host_last_error", "pem_write_result_files", "pem_csv_append", "pem_write_mtx_csr"]
@@ -24,7 +25,41 @@ class CsvRecord(C.Structure):
                 ("kernel_ms", C.c_double), ("malloc_ms", C.c_double), ("gflops", C.c_double)]
 
 
+MGPU_SYMBOLS = ["pem_mgpu_create", "pem_mgpu_destroy", "pem_mgpu_size", "pem_mgpu_ctx", "pem_mgpu_slice_offsets", "pem_mgpu_rebase_rowptr",
+                "pem_mgpu_gather_csr"]
+
 _lib = None
+_mgpu = None
+
+
+def mgpu_lib():
+    """libpemmgpu.so (links RCCL); the C++ tool's `--gpus N` path.  Loads without a GPU; creating contexts needs one."""
+    global _mgpu
+    if _mgpu is None:
+        if not os.path.exists(MGPU_LIB_PATH):
+            raise ImportError(f"{MGPU_LIB_PATH} is missing: run __graft_entry__.build()")
+        C.CDLL(os.path.join(_HERE, "libpemspgemm_hip.so"), mode=C.RTLD_GLOBAL)
+        _mgpu = C.CDLL(MGPU_LIB_PATH)
+    return _mgpu
+
+
+def mgpu_assemble_rowptr(slice_rowptrs, nnzs):
+    """the host arithmetic of pem_mgpu_gather_csr: (row_off, nnz_off, assembled rowptr) for CSR slices given by their
+    relative row pointers and entry counts"""
+    n = len(slice_rowptrs)
+    L = mgpu_lib()
+    sl = [np.ascontiguousarray(r, np.int32) for r in slice_rowptrs]
+    nrows = np.array([len(r) - 1 for r in sl], np.int64)
+    nnz = np.array(nnzs, np.int64)
+    row_off, nnz_off = np.zeros(n + 1, np.int64), np.zeros(n + 1, np.int64)
+    p64 = C.POINTER(C.c_int64)
+    L.pem_mgpu_slice_offsets(n, nrows.ctypes.data_as(p64), nnz.ctypes.data_as(p64), row_off.ctypes.data_as(p64), nnz_off.ctypes.data_as(p64))
+    out = np.zeros(int(row_off[n]) + 1, np.int32)
+    ptrs = (C.POINTER(C.c_int32) * n)(*[r.ctypes.data_as(C.POINTER(C.c_int32)) for r in sl])
+    L.pem_mgpu_rebase_rowptr(n, nrows.ctypes.data_as(p64), ptrs, row_off.ctypes.data_as(p64), nnz_off.ctypes.data_as(p64),
+                             out.ctypes.data_as(C.POINTER(C.c_int32)))
+    return row_off, nnz_off, out
+
 
 
 def lib():

@@ -35,6 +35,33 @@ def test_host_library_exports_every_declared_symbol(pkg):
     assert sorted(hostio.HOST_SYMBOLS) == declared
 
 
+def test_mgpu_library_exports_and_assembles_row_pointers(pkg):
+    """libpemmgpu.so (the C++ tool's --gpus N path over RCCL): every declared symbol is exported, and the host arithmetic
+    of the gather -- where each rank's slice lands, row pointers rebased by the entries in front -- equals numpy's."""
+    import numpy as np
+    hostio = importlib.import_module("pem_spgemm_amd.hostio")
+    lib = hostio.mgpu_lib()
+    declared = _declared("pem_mgpu.h")
+    for sym in declared:
+        assert hasattr(lib, sym), f"libpemmgpu.so does not export {sym}"
+    assert sorted(hostio.MGPU_SYMBOLS) == declared
+    rng = np.random.default_rng(7)
+    for n in (1, 2, 3, 8):
+        lens = [rng.integers(0, 6, int(rng.integers(0, 40))) for _ in range(n)]            # per-row entry counts of every slice
+        if n >= 3:
+            lens[1] = np.zeros(0, np.int64)                                                 # a rank with no rows at all
+        slices = [np.concatenate([[0], np.cumsum(l)]).astype(np.int32) for l in lens]
+        row_off, nnz_off, rowptr = hostio.mgpu_assemble_rowptr(slices, [int(s[-1]) for s in slices])
+        want = np.concatenate([[0], np.cumsum(np.concatenate(lens))]).astype(np.int32) if n else np.zeros(1, np.int32)
+        assert np.array_equal(rowptr, want)
+        assert np.array_equal(row_off, np.concatenate([[0], np.cumsum([len(l) for l in lens])]))
+        assert np.array_equal(nnz_off, np.concatenate([[0], np.cumsum([int(l.sum()) for l in lens])]))
+    if not __import__("torch").cuda.is_available():
+        m = C.c_void_p()
+        devs = (C.c_int * 1)(0)
+        assert lib.pem_mgpu_create(1, devs, C.byref(m)) == -7       # PEM_E_NODEVICE: no CPU fallback here either
+
+
 def test_no_gpu_means_loud_failure(pkg):
     import torch
     if torch.cuda.is_available():

@@ -166,6 +166,34 @@ def test_cage15_rank_slice_against_cpu_port(pkg, oracle, standins, ctx):
     assert np.array_equal(v, v0)
 
 
+def test_cli_gpus_path_gathers_through_rccl_library(pkg, oracle, standins, tmp_path):
+    """`pemspgemm --gpus N` (one context per device, slices gathered by libpemmgpu.so over RCCL): with the one GPU of this
+    box the communicator has one rank, but conversion per rank, the row split, the threaded passes, the device CSR export
+    and the assembly all run -- the result files must equal the oracle's C, like the single-device path's."""
+    import scipy.io
+    hostio = importlib.import_module("pem_spgemm_amd.hostio")
+    rows, cols, I, J, V = standins.make("scircuit", scale=0.01)
+    mtx, fc = str(tmp_path / "mini.mtx"), str(tmp_path / "C.mtx")
+    standins.write_mtx(mtx, rows, cols, I, J, V)
+    env = dict(os.environ, PEM_RESULT_DIR=str(tmp_path), PEM_CSV=str(tmp_path / "r.csv"), PEM_REPEAT="2")
+    out = subprocess.run([hostio.CLI_PATH, mtx, "1", "--gpus", "1", "--out", fc], env=env, capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "gather of C to GPU 0 over RCCL" in out.stdout and "1 GPUs" in out.stdout
+    a = oracle.Csr(rows, cols, I, J, V)
+    rp, ci, v = oracle.csr_spgemm(a, a).arrays()
+    assert int((tmp_path / "SPGEMM_RESULT_NNZ.txt").read_text()) == len(ci)
+    assert np.array_equal(np.loadtxt(tmp_path / "SPGEMM_RESULT_COLS.txt", dtype=np.int64, ndmin=1), ci)
+    assert np.array_equal(np.loadtxt(tmp_path / "SPGEMM_RESULT_ROWS.txt", dtype=np.int64, ndmin=1), np.repeat(np.arange(rows), np.diff(rp)))
+    C = scipy.io.mmread(fc).tocsr()
+    C.sort_indices()
+    assert np.array_equal(C.indptr, rp) and np.array_equal(C.indices, ci) and np.array_equal(C.data, v)
+    rec = (tmp_path / "r.csv").read_text().split("\n")[1].split(",")
+    assert rec[14] == "1" and float(rec[20]) > 0 and len(rec) == 22          # gpus, first-pass ms, gather ms
+    # a device that does not exist is refused, not ignored
+    out = subprocess.run([hostio.CLI_PATH, mtx, "0", "--gpus", "64"], env=env, capture_output=True, text=True, timeout=180)
+    assert out.returncode == 2 and "visible" in out.stderr
+
+
 def test_cli_distinct_b_and_mtx_output(pkg, oracle, standins, tmp_path):
     """C = A*B with two files and a Matrix-Market result (beyond the reference's A^2 / A*A^T)."""
     import scipy.io
