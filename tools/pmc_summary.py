@@ -16,12 +16,12 @@ for path in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), r
     with open(path) as f:
         for row in csv.DictReader(f):
             name = row.get("Kernel_Name", "")
-            short = name.split("(")[0].replace("pem::", "").replace("void ", "")
+            short = name.split("(")[0].replace("pem::", "").replace("void ", "").replace(", false>", ">").replace(", true>", ",deep>")
             per[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for path in glob.glob(os.path.join(out, "sq", "**", "*kernel_trace.csv"), recursive=True):
     with open(path) as f:
         for row in csv.DictReader(f):
-            short = row["Kernel_Name"].split("(")[0].replace("pem::", "").replace("void ", "")
+            short = row["Kernel_Name"].split("(")[0].replace("pem::", "").replace("void ", "").replace(", false>", ">").replace(", true>", ",deep>")
             dur[short].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
 cols = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_LDS",
         "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]
@@ -44,5 +44,13 @@ for _, k, n, d, avg in rows:
     f, w = avg["FETCH_SIZE"], avg["WRITE_SIZE"]
     if f == f and w == w:
         traffic[k.strip()] = dict(hbm_bytes_per_launch=f + w, fetch_bytes=f, write_bytes=w, avg_us=d)
+# which kernel sources the table belongs to: bench.py only quotes it for the same sources
+import hashlib
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_h = hashlib.sha256()
+for _f in ("primitives.hip", "convert.hip", "spgemm.hip"):
+    with open(os.path.join(_root, "pem-spgemm_amd", "csrc", _f), "rb") as _fh:
+        _h.update(_fh.read())
+traffic["__meta__"] = dict(kernels_sha=_h.hexdigest()[:16], source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 (gfx950)")
 with open(os.path.join(out, "pmc_traffic.json"), "w") as fh:
     json.dump(traffic, fh, indent=1, sort_keys=True)
