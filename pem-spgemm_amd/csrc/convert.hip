@@ -171,15 +171,17 @@ __global__ void conv_vals_t_kernel(const uint8_t *__restrict__ rowcolidx, const 
 }
 
 // a7 (spgemm.cu:986-1031): tile-level CSR from the sorted tile list -- boundary fill, no
-// reduce_by_key / scatter / scan needed.
+// reduce_by_key / scatter / scan needed.  Also the packed (tile column, occupancy) record step 1 expands products from.
 __global__ void conv_tile_csr_kernel(const long long *__restrict__ tile_keys, long long ntiles, int tile_rows,
-                                     int *__restrict__ tile_rowptr, int *__restrict__ tile_colidx)
+                                     int *__restrict__ tile_rowptr, int *__restrict__ tile_colidx, const uint32_t *__restrict__ occ,
+                                     int2 *__restrict__ colocc)
 {
     long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     long long k = tile_keys[t];
     int tr = (int)(k >> 32);
     tile_colidx[t] = (int)(k & 0xFFFFFFFFll);
+    colocc[t] = make_int2((int)(k & 0xFFFFFFFFll), (int)occ[t]);
     int prev = t > 0 ? (int)(tile_keys[t - 1] >> 32) : -1;
     for (int row = prev + 1; row <= tr; ++row) tile_rowptr[row] = (int)t;
     if (t == ntiles - 1)
@@ -392,6 +394,7 @@ static pem_status derive_tiled(pem_ctx *ctx, pem_tiled *T, const int *headx, int
     PEM_TRY(T->rowptr.reserve(16 * (nt + 1)));
     PEM_TRY(T->tile_rec.reserve(sizeof(uint32_t) * 16 * (nt + 1)));
     PEM_TRY(T->tile_occ.reserve(sizeof(uint32_t) * (nt + 4)));
+    PEM_TRY(T->tile_colocc.reserve(sizeof(int2) * (nt + 4)));
     PEM_TRY(T->tile_rec_t.reserve(sizeof(uint32_t) * 16 * (nt + 1)));
     PEM_TRY(T->vals_t.reserve((size_t)T->value_bytes * (nnz + 1)));
     PEM_TRY(T->tile_rowptr.reserve(sizeof(int) * ((size_t)T->tile_rows + 4)));
@@ -415,7 +418,7 @@ static pem_status derive_tiled(pem_ctx *ctx, pem_tiled *T, const int *headx, int
     PEM_HIP(hipEventRecord(ctx->ev[7], st));
     if (nt) {
         PEM_LAUNCH(ctx, conv_tile_csr_kernel, grid_for(nt, 256), 256, T->tile_keys.as<long long>(), (long long)ntiles, T->tile_rows,
-                   T->tile_rowptr.as<int>(), T->tile_colidx.as<int>());
+                   T->tile_rowptr.as<int>(), T->tile_colidx.as<int>(), T->tile_occ.as<uint32_t>(), T->tile_colocc.as<int2>());
         // column-major order of the tiles: second (small) radix sort, payload = CSR tile id
         DevBuf &k0 = ctx->tmp[8], &k1 = ctx->tmp[9], &v0 = ctx->tmp[10], &v1 = ctx->tmp[11];   // context-owned, grow-only
         PEM_TRY(k0.reserve(sizeof(uint64_t) * nt));

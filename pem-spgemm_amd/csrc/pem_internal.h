@@ -189,6 +189,7 @@ struct pem_tiled {
     pem::DevBuf tile_rec;             // derived: uint32[16T] = masks[16t+r] | rowptr[16t+r] << 16 (one gather serves step 3)
     pem::DevBuf tile_rec_t;           // derived: uint32[16T] = masks_t[16t+c] | (entries in columns < c) << 16: the B side of step 3
     pem::DevBuf vals_t;               // derived: double[nnz], the tile's values in column-major order (read with tile_rec_t)
+    pem::DevBuf tile_colocc;          // derived: int2[T] = (tile_colidx, tile_occ): step 1's expansion reads both of every B tile
     pem::DevBuf tile_occ;             // derived: uint32[T] = occupied columns (low 16 bits) | occupied rows << 16 (step-1 pruning)
     std::vector<int> h_tile_rowptr;   // host copy (tile_rows+1 ints) for plan creation / splits
 };

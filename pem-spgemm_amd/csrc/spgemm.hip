@@ -404,8 +404,7 @@ struct S1Row {
     static constexpr bool COARSE_OK = THREADS >= 256;
     static constexpr bool ORDERED = THREADS == 1024;   // live keys compacted in product order (see expand_compact)
     int R, a0, n, a_lo, prune;
-    const int *b_tile_colidx;
-    const uint32_t *b_occ;
+    const int2 *b_colocc;          // per B tile: (tile column, occupancy word) -- one 8-byte gather gives the key and the pruning test
     struct Product {
         int a, b;          // operand tile ids
         unsigned acol;     // occupied columns of the A tile
@@ -432,8 +431,9 @@ struct S1Row {
     {
         if (q >= n) return ~KeyT(0);
         const Product pr = tile_b(q, prune != 0);
-        if (prune && !(pr.acol & (b_occ[pr.b] >> 16))) return ~KeyT(0);
-        return (KeyT(b_tile_colidx[pr.b]) << QB) | KeyT(q);
+        const int2 co = b_colocc[pr.b];
+        if (prune && !(pr.acol & ((unsigned)co.y >> 16))) return ~KeyT(0);
+        return (KeyT(co.x) << QB) | KeyT(q);
     }
     // expand all n products of the row, keep the live ones: their keys are packed into keys[0..nlive) in
     // arbitrary order (ballot + one LDS atomic per wave and chunk) -- the sort that follows fixes the order,
@@ -647,8 +647,8 @@ template <typename KeyT, int CAP, int QB, int THREADS, int RCAP>
 __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || sizeof(KeyT) == 8 ? 4 : 8) : 1) s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr,
                                                              int tr_lo, int a_lo, const int *__restrict__ a_tile_colidx,
                                                              const int *__restrict__ acnt, const int *__restrict__ row_n, const int *__restrict__ row_lbase,
-                                                             const int *__restrict__ b_tile_rowptr, const int *__restrict__ b_tile_colidx,
-                                                             const uint32_t *__restrict__ a_occ, const uint32_t *__restrict__ b_occ, int prune,
+                                                             const int *__restrict__ b_tile_rowptr, const int2 *__restrict__ b_colocc,
+                                                             const uint32_t *__restrict__ a_occ, int prune,
                                                              int *__restrict__ pairs_a, int *__restrict__ pairs_b,
                                                              int *__restrict__ scratch_col, int *__restrict__ scratch_off,
                                                              int2 *__restrict__ block_info, int *__restrict__ row_tc, int key_bits)
@@ -685,9 +685,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
         row.rbs = rbs;
         row.rco = rco;
         row.prune = prune;
-        row.b_occ = b_occ;
         row.a_lo = a_lo;
-        row.b_tile_colidx = b_tile_colidx;
+        row.b_colocc = b_colocc;
         row.a0 = a_tile_rowptr[tr_lo + i] - a_lo;
         row.R = a_tile_rowptr[tr_lo + i + 1] - a_lo - row.a0;   // <= RCAP: the row classification saw to that
         row.n = row_n[i];
@@ -1727,8 +1726,7 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
         PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<" #CAP ">", (s1_rowsort_kernel<KeyT, CAP, QB, THREADS, RCAP>), grid, THREADS,             \
                          rl + (size_t)(BIN) * mt, counts[BIN], A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, A->tile_colidx.as<int>(), \
                          p->aprod_off.as<int>(), p->row_n.as<int>(), p->row_lbase.as<int>(), B->tile_rowptr.as<int>(),              \
-                         B->tile_colidx.as<int>(),                                                                                     \
-                         A->tile_occ.as<uint32_t>(), B->tile_occ.as<uint32_t>(), prune, p->pairs_a.as<int>(), p->pairs_b.as<int>(),   \
+                         B->tile_colocc.as<int2>(), A->tile_occ.as<uint32_t>(), prune, p->pairs_a.as<int>(), p->pairs_b.as<int>(),     \
                          p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->block_info.as<int2>(), p->c_tile_rowptr.as<int>(),     \
                          key_bits);                                                                                                    \
     }
