@@ -1,6 +1,7 @@
 """GPU: 2-D (row block of A) x (column block of B) partition, emulated on one card: every block of the
 grid is computed by its own pair of partial tilings -- no tiling ever holds all of A or of B -- and the spliced blocks
-must equal the one-plan result bit for bit (structure and values: each entry still sums its full k range in order)."""
+must equal the ORACLE's C (the serial CSR Gustavson port, float chain for fp32) bit for bit -- structure and values: each
+entry still sums its full k range in order -- and, as a second check, the one-plan HIP result."""
 import importlib
 
 import numpy as np
@@ -43,8 +44,15 @@ def test_grid_blocks_splice_to_the_full_result(pkg, oracle, ctx, name, nrb, ncb,
             p.spgemm()
             blocks.append(tuple(torch.from_numpy(x) for x in p.export_csr()))
     rp, ci, v = mg.assemble_csr_blocks(blocks, ncb)
+    # parity proper: against the CPU oracle on the same inputs (fp32: operands rounded to float, one fmaf per product)
+    f32 = dtype == np.float32
+    oa, ob = oracle.Csr(rows, cols, I, J, V.astype(np.float64), False), oracle.Csr(rows, cols, I, J, V.astype(np.float64), tr)
+    orp, oci, ov = oracle.csr_spgemm(oa, ob, 1, f32=f32).arrays()
+    assert np.array_equal(rp.numpy(), orp) and np.array_equal(ci.numpy(), oci)
+    assert v.numpy().dtype == dtype and np.array_equal(v.numpy().astype(np.float64), ov)
+    # ... and the one-plan result of the HIP path itself
     assert np.array_equal(rp.numpy(), frp) and np.array_equal(ci.numpy(), fci)
-    assert v.numpy().dtype == dtype and np.array_equal(v.numpy(), fv)
+    assert np.array_equal(v.numpy(), fv)
     if nrb > 1 and len(I) > 1000:
         assert held_a < len(I)          # no block's tiling held all of A ...
     if ncb > 1 and len(I) > 1000:

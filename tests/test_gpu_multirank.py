@@ -27,10 +27,35 @@ def _run(n, extra, launcher=True):
     return json.loads(line)
 
 
+def _oracle_fingerprint(workload, scale, aat=False):
+    """the fingerprint bench.py prints for the gathered C, computed from the CPU oracle's C of the same stand-in"""
+    import importlib
+    import numpy as np
+    import __graft_entry__ as g
+    g.load_package()
+    standins = importlib.import_module("pem_spgemm_amd.standins")
+    o = g.load_oracle()
+    rows, cols, I, J, V = standins.make(workload, scale)
+    a = o.Csr(rows, cols, I, J, V, False)
+    b = o.Csr(rows, cols, I, J, V, True) if aat else a
+    rp, ci, v = o.csr_spgemm(a, b, o.max_threads()).arrays()
+    return dict(rows=len(rp) - 1, nnz=len(ci), rowptr_last=int(rp[-1]), colidx_sum=int(ci.astype(np.int64).sum()),
+                rowptr_sum=int(rp.astype(np.int64).sum()), vals_sum=float(v.sum()), vals_abs_sum=float(np.abs(v).sum()))
+
+
+def _same_matrix(got, want):
+    """equal CSR arrays give equal integer sums; the value sums are taken in different orders (torch vs numpy)"""
+    for k in ("rows", "nnz", "rowptr_last", "colidx_sum", "rowptr_sum"):
+        assert got[k] == want[k], k
+    assert abs(got["vals_sum"] - want["vals_sum"]) <= 1e-9 * want["vals_abs_sum"]
+    assert abs(got["vals_abs_sum"] - want["vals_abs_sum"]) <= 1e-9 * want["vals_abs_sum"]
+
+
 def test_two_ranks_on_one_card_agree_with_one_rank():
     one = _run(1, ["--workload", "scircuit", "--scale", "0.25"])
     two = _run(2, ["--workload", "scircuit", "--scale", "0.25"])
     assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "rowblock2+gather"
+    _same_matrix(two["exchange"]["gathered"], _oracle_fingerprint("scircuit", 0.25))     # the gathered C is the oracle's C
     for k in ("flop", "C_nnz", "C_tiles", "tile_pairs", "nnz"):
         assert one["config"][k] == two["config"][k], k
     assert two["value"] > 0 and two["scaling"] == "strong"
@@ -48,6 +73,7 @@ def test_two_ranks_a_at_row_blocks_tile_only_their_rows():
     for k in ("flop", "C_nnz", "C_tiles", "tile_pairs", "nnz"):
         assert one["config"][k] == two["config"][k], k
     assert two["exchange"]["gathered"]["nnz"] == one["config"]["C_nnz"]
+    _same_matrix(two["exchange"]["gathered"], _oracle_fingerprint("mc2depi", 0.05, aat=True))
 
 
 def test_grid_partition_on_one_card_gathers_the_same_matrix():
@@ -60,6 +86,7 @@ def test_grid_partition_on_one_card_gathers_the_same_matrix():
         assert two["config"][k] == grid["config"][k], k
     g2, g4 = two["exchange"]["gathered"], grid["exchange"]["gathered"]
     assert g2 == g4 and g2["nnz"] == two["config"]["C_nnz"] == g2["rowptr_last"]
+    _same_matrix(g4, _oracle_fingerprint("scircuit", 0.25))
     aat = _run(3, ["--workload", "mc2depi", "--scale", "0.05", "--grid", "1x3"])          # A*A^T, B split only
     ref = _run(1, ["--workload", "mc2depi", "--scale", "0.05"])
     assert aat["config"]["flop"] == ref["config"]["flop"] and aat["config"]["C_nnz"] == ref["config"]["C_nnz"]
