@@ -221,6 +221,8 @@ struct pem_cplan {
     // row-local step 1
     pem::DevBuf row_list, bin_count, xl_base, xl_rowstart, scratch_col, scratch_off;
     bool pairs_ready = false;          // step 1 already wrote pairs_a / pairs_b
+    bool verify_folded = false;        // this pass's size check ran inside s2_entries_kernel
+    bool group_nnz_cleared = false;    // step 1's reset already zeroed group_nnz for this pass
     bool wide = true;                  // step 2 ran the fused kernel (step 3 then runs entry-per-lane); false: 16-lanes-per-tile baseline
     bool compact_valid = false;        // c_tile_colidx / pairs_offset hold the dense layout (else: row-local scratch, see ensure_compact)
     pem::DevBuf block_info;            // int2 per 256-slot block of the step-1 scratch: (tile row of the block's first slot, its position in the row's range)

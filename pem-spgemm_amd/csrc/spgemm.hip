@@ -17,6 +17,7 @@
 // the reference layouts (include/pem_spgemm.h).  Environment switches (A/B baselines kept for tests):
 //   PEM_STEP1=esc  PEM_WIDE=0  PEM_PRUNE=0  PEM_NO_WARM=1  PEM_EXPORT=rows
 #include "pem_internal.h"
+#include <algorithm>
 #include <chrono>
 
 using namespace pem;
@@ -199,7 +200,7 @@ constexpr int S1_COARSE = 512;   // 64-product blocks indexed per row (covers th
 
 __global__ void __launch_bounds__(256) s1_reset_kernel(int *__restrict__ flags, int *__restrict__ bin_count, long long *__restrict__ scalars,
                                                        int *__restrict__ pairs_offset, int *__restrict__ row_tc, int mt, int *__restrict__ row_n,
-                                                       int *__restrict__ row_l)
+                                                       int *__restrict__ row_l, int *__restrict__ group_nnz, int ngroups)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < NUM_FLAGS) flags[i] = 0;
@@ -213,6 +214,7 @@ __global__ void __launch_bounds__(256) s1_reset_kernel(int *__restrict__ flags, 
         row_n[i] = 0;
         row_l[i] = 0;
     }
+    if (i < ngroups) group_nnz[i] = 0;   // entry counts per S2_GROUP tiles, accumulated by s2_tiles_kernel (repeat passes: size known)
 }
 
 __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int mt,
@@ -1178,12 +1180,30 @@ __global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ s
 // a11's offsets + a12 (spgemm.cu:546, 1288, 552-591), one C tile per lane, S2_GROUP tiles per block: entry offsets =
 // the group's base (scanned group counts) + a block scan of the masks' popcounts; the (r<<4|c) bytes; and, for step 3,
 // the tile every S3_CHUNK-entry chunk of C starts in.
+// repeat pass on an unchanged plan: the sizes the host assumed (from the previous pass) against what this pass computed
+struct WarmCheck {
+    int on;
+    long long P, Pall, TC, nnz, nxl;
+    int c0, c1, c2, c3;
+};
+__device__ __forceinline__ void warm_check(const WarmCheck &w, const long long *__restrict__ d_scalars, const int *__restrict__ bin_count,
+                                           int *__restrict__ flags)
+{
+    if (d_scalars[0] != w.P || d_scalars[1] != w.TC || d_scalars[2] != w.nnz || d_scalars[3] != w.Pall || bin_count[0] != w.c0 ||
+        bin_count[1] != w.c1 || bin_count[2] != w.c2 || bin_count[3] != w.c3 || bin_count[5] != w.nxl)
+        flags[FLAG_CAPACITY] = 1;
+}
+
 __global__ void __launch_bounds__(S2_GROUP) s2_entries_kernel(const uint32_t *__restrict__ c_mask, long long ntc, const int *__restrict__ group_base,
                                                               long long cap_nnz, int *__restrict__ c_tile_nnz_ptr, uint8_t *__restrict__ c_rowcolidx,
-                                                              int *__restrict__ chunk_tile, int *__restrict__ flags)
+                                                              int *__restrict__ chunk_tile, int *__restrict__ flags, WarmCheck wc,
+                                                              const long long *__restrict__ d_scalars, const int *__restrict__ bin_count)
 {
     __shared__ int w_nnz[S2_GROUP / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // every size of the pass is final by now (the entry total came out of the group scan just before this launch): the
+    // check of a repeat pass rides along instead of taking a launch of its own at the end
+    if (wc.on && blockIdx.x == 0 && tid == 0) warm_check(wc, d_scalars, bin_count, flags);
     const long long t = (long long)blockIdx.x * S2_GROUP + tid;
     unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (t < ntc) {
@@ -1555,13 +1575,9 @@ __global__ void split_rowprod_kernel(const int *__restrict__ a_tile_rowptr, cons
 }
 
 
-// repeat pass on an unchanged plan: the sizes the host assumed (from the previous pass) against what this pass computed
-__global__ void warm_verify_kernel(const long long *__restrict__ d_scalars, const int *__restrict__ bin_count, long long P, long long Pall, long long TC,
-                                   long long nnz, int c0, int c1, int c2, int c3, long long nxl, int *__restrict__ flags)
+__global__ void warm_verify_kernel(const long long *__restrict__ d_scalars, const int *__restrict__ bin_count, WarmCheck wc, int *__restrict__ flags)
 {
-    if (d_scalars[0] != P || d_scalars[1] != TC || d_scalars[2] != nnz || d_scalars[3] != Pall || bin_count[0] != c0 || bin_count[1] != c1 || bin_count[2] != c2 ||
-        bin_count[3] != c3 || bin_count[5] != nxl)
-        flags[FLAG_CAPACITY] = 1;
+    warm_check(wc, d_scalars, bin_count, flags);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1809,9 +1825,18 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     // and the per-row product totals; the per-row tile counts in c_tile_rowptr are zeroed by the row classification below
     PEM_TRY(p->row_n.reserve(sizeof(int) * ((size_t)mt + 4)));
     PEM_TRY(p->row_lbase.reserve(sizeof(int) * ((size_t)mt + 4)));
-    PEM_LAUNCH(ctx, s1_reset_kernel, grid_for((size_t)mt + 1, 256), 256, ctx->d_flags, p->bin_count.as<int>(),
+    // (a repeat pass knows T_C, so the reset also clears step 2's group counters and saves it a memset)
+    int ngroups_reset = 0;
+    p->group_nnz_cleared = false;
+    if (p->warm_pass && p->w_TC > 0) {
+        ngroups_reset = (int)((p->w_TC + S2_GROUP - 1) / S2_GROUP) + 4;
+        PEM_TRY(p->group_nnz.reserve(sizeof(int) * (size_t)ngroups_reset));
+        p->group_nnz_cleared = true;
+    }
+    const size_t reset_n = std::max((size_t)mt + 1, (size_t)ngroups_reset);
+    PEM_LAUNCH(ctx, s1_reset_kernel, grid_for(reset_n, 256), 256, ctx->d_flags, p->bin_count.as<int>(),
                reinterpret_cast<long long *>(ctx->d_scalars), p->pairs_offset.as<int>(), p->c_tile_rowptr.as<int>(), mt, p->row_n.as<int>(),
-               p->row_lbase.as<int>());
+               p->row_lbase.as<int>(), p->group_nnz.as<int>(), ngroups_reset);
     // products per A tile (all: expansion; live: what is sorted and stored) and their totals per tile row.  The only scan
     // left is the one over the ROWS' live totals (row r's pairs, and its C tile slots, start at row_lbase[r]); offsets inside
     // a row are rebuilt in LDS by the row's workgroup, and the grand total of all products is only ever a 64-bit scalar --
@@ -1972,6 +1997,7 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
     // PEM_WIDE=0 take the 16-lanes-per-tile baseline kernels over the dense layout
     const bool fused = p->pairs_ready && !(wide_env && !strcmp(wide_env, "0"));
     p->wide = fused;
+    p->verify_folded = false;
     int64_t nnzc = 0;
     if (fused) {
         PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
@@ -1980,7 +2006,7 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
             // entry counts of every S2_GROUP tiles, accumulated by s2_tiles_kernel
             const size_t nblk = (n + 255) / 256, ngroups = (ntc + S2_GROUP - 1) / S2_GROUP;
             PEM_TRY(p->group_nnz.reserve(sizeof(int) * (ngroups + 4)));
-            PEM_HIP(hipMemsetAsync(p->group_nnz.p, 0, sizeof(int) * (ngroups + 4), st));
+            if (!p->group_nnz_cleared) PEM_HIP(hipMemsetAsync(p->group_nnz.p, 0, sizeof(int) * (ngroups + 4), st));
             int *group_nnz = p->group_nnz.as<int>();
             PEM_LAUNCH(ctx, s2_tiles_kernel, (unsigned)nblk, 256, p->scratch_col.as<int>(), p->scratch_off.as<int>(), (long long)n,
                        p->block_info.as<int2>(), p->c_tile_rowptr.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), A->masks.as<uint16_t>(),
@@ -2002,8 +2028,12 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
             }
             PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
             PEM_TRY(p->s3_chunk_tile.reserve(sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)));
+            WarmCheck wc = {};
+            if (p->warm_pass) wc = WarmCheck{1, p->w_P, p->w_Pall, p->w_TC, p->w_nnz, p->w_nxl, p->w_counts[0], p->w_counts[1], p->w_counts[2], p->w_counts[3]};
+            p->verify_folded = p->warm_pass;
             PEM_LAUNCH(ctx, s2_entries_kernel, (unsigned)((ntc + S2_GROUP) / S2_GROUP), S2_GROUP, p->c_mask.as<uint32_t>(), (long long)ntc, group_nnz,
-                       (long long)nnzc, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->s3_chunk_tile.as<int>(), ctx->d_flags);
+                       (long long)nnzc, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->s3_chunk_tile.as<int>(), ctx->d_flags, wc,
+                       reinterpret_cast<const long long *>(ctx->d_scalars), p->bin_count.as<int>());
             p->compact_valid = true;
         } else {
             PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_nnz_ptr.as<int>(), p->c_tile_nnz_ptr.as<int>(), 0, ctx->d_scalars + 2));
@@ -2141,9 +2171,10 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
         ~Chain() { c->chain_events = false; }
     } chain(ctx);
     auto launch_verify = [&]() {
-        PEM_LAUNCH(ctx, warm_verify_kernel, 1, 1, reinterpret_cast<const long long *>(ctx->d_scalars), plan->bin_count.as<int>(),
-                   (long long)plan->w_P, (long long)plan->w_Pall, (long long)plan->w_TC, (long long)plan->w_nnz, plan->w_counts[0], plan->w_counts[1], plan->w_counts[2],
-                   plan->w_counts[3], (long long)plan->w_nxl, ctx->d_flags);
+        if (plan->verify_folded) return;   // step 2's last kernel has already compared the sizes
+        const WarmCheck wc = {1, plan->w_P, plan->w_Pall, plan->w_TC, plan->w_nnz, plan->w_nxl, plan->w_counts[0], plan->w_counts[1],
+                              plan->w_counts[2], plan->w_counts[3]};
+        PEM_LAUNCH(ctx, warm_verify_kernel, 1, 1, reinterpret_cast<const long long *>(ctx->d_scalars), plan->bin_count.as<int>(), wc, ctx->d_flags);
     };
     // Graph replay (pem_set_graph_replay): a repeat pass has fixed grids, sizes and buffer addresses, so its ~28 launches,
     // the fork onto the auxiliary streams and the joins are captured once and replayed as one hipGraph -- the launch
