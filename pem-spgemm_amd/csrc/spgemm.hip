@@ -1295,6 +1295,15 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
         const long long tl = t0 + lane < ntc ? t0 + lane : ntc - 1;
         const int my_off = (t0 + lane < ntc) ? c_tile_nnz_ptr[tl] : 0x7FFFFFFF;   // value offset of tile t0+lane
         const int my_p0 = pairs_offset[tl], my_p1 = pairs_offset[tl + 1];
+        // the tile's FIRST pair and its operands' value offsets, one gather set per tile: 92 % of webbase-1M's C tiles have
+        // one pair, so most entries get their whole pair record by shuffle instead of four loads of their own (the step is
+        // bound by the number of vector-memory instructions, section 4 of DESIGN.md)
+        const int my_a0 = pairs_a[my_p0], my_b0 = pairs_b[my_p0];
+        const int my_av0 = a_nnz_ptr[my_a0], my_bv0 = b_nnz_ptr[my_b0];
+        // ... and the second pair of the tiles that have one (7 %): their entries' second trip then costs 4 instructions, not 8
+        const bool two = my_p1 - my_p0 >= 2;
+        const int my_a1 = two ? pairs_a[my_p0 + 1] : 0, my_b1 = two ? pairs_b[my_p0 + 1] : 0;
+        const int my_av1 = two ? a_nnz_ptr[my_a1] : 0, my_bv1 = two ? b_nnz_ptr[my_b1] : 0;
         const long long tend = t0 + 64 < ntc ? t0 + 64 : ntc;
         const int chunk_end = c_tile_nnz_ptr[tend];
         const int first = __shfl(my_off, 0, 64);
@@ -1311,11 +1320,44 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
             if (probe <= e) ti += step;
         }
         const int p0 = __shfl(my_p0, ti, 64), p1 = __shfl(my_p1, ti, 64);
+        const int a0 = __shfl(my_a0, ti, 64), b0 = __shfl(my_b0, ti, 64), av0 = __shfl(my_av0, ti, 64), bv0 = __shfl(my_bv0, ti, 64);
+        // (every shuffle sits in front of the `continue`: a lane that has left cannot be read from)
+        const int a1 = __shfl(my_a1, ti, 64), b1 = __shfl(my_b1, ti, 64), av1 = __shfl(my_av1, ti, 64), bv1 = __shfl(my_bv1, ti, 64);
         if (!valid) continue;
         const unsigned rc = c_rowcolidx[e];
         const int r = rc >> 4, c = rc & 15;
         VT acc = VT(0);
         int p = p0;
+        if (!DEEP) {   // first pair: everything but the two records and the values is already here
+            const unsigned aw = a_rec[16 * (size_t)a0 + r], bw = b_rec_t[16 * (size_t)b0 + c];
+            const unsigned am = aw & 0xFFFFu, bm = bw & 0xFFFFu;
+            unsigned m = am & bm;
+            const VT *av = a_vals + av0 + (aw >> 16);
+            const VT *bv = b_vals_t + bv0 + (bw >> 16);
+            while (m) {
+                const int kk = __builtin_ctz(m);
+                m &= m - 1;
+                const unsigned below = (1u << kk) - 1u;
+                acc = pem_fma(av[__popc(am & below)], bv[__popc(bm & below)], acc);
+            }
+            ++p;
+            {
+                if (p < p1) {             // second pair
+                    const unsigned aw1 = a_rec[16 * (size_t)a1 + r], bw1 = b_rec_t[16 * (size_t)b1 + c];
+                    const unsigned am1 = aw1 & 0xFFFFu, bm1 = bw1 & 0xFFFFu;
+                    unsigned m1 = am1 & bm1;
+                    const VT *av = a_vals + av1 + (aw1 >> 16);
+                    const VT *bv = b_vals_t + bv1 + (bw1 >> 16);
+                    while (m1) {
+                        const int kk = __builtin_ctz(m1);
+                        m1 &= m1 - 1;
+                        const unsigned below = (1u << kk) - 1u;
+                        acc = pem_fma(av[__popc(am1 & below)], bv[__popc(bm1 & below)], acc);
+                    }
+                    ++p;
+                }
+            }
+        }
         // DEEP (plans averaging two or more pairs per C tile: 3.1 on cage15-class inputs, 30+ where a band multiplies
         // itself): four pairs per trip, their eight record gathers in flight together instead of four dependent round
         // trips; the products are still added pair by pair in ascending order.  cage15 slice: 17.3 -> 14.7 ms.  Not for
