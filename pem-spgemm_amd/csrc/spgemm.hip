@@ -43,19 +43,41 @@ __global__ void __launch_bounds__(256) s1_aprod_kernel(const int *__restrict__ a
     const int arel = (blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int l = threadIdx.x & (G - 1);
     const bool in = arel < nA;
-    int len = 0, cnt = 0;
+    constexpr int LONG = 64 * G;   // a B tile row this long is walked by the whole wave, not by the tile's G lanes
+    int len = 0, cnt = 0, b0 = 0;
+    unsigned acol = 0;
     if (in) {
         const int k = a_tile_colidx[a_lo + arel];
-        const int b0 = b_tile_rowptr[k];
+        b0 = b_tile_rowptr[k];
         len = b_tile_rowptr[k + 1] - b0;
         if (prune) {
-            const unsigned acol = a_occ[a_lo + arel] & 0xFFFFu;
+            acol = a_occ[a_lo + arel] & 0xFFFFu;
+            if (len < LONG) {
 #pragma unroll 4
-            for (int q = l; q < len; q += G) cnt += (acol & (b_occ[b0 + q] >> 16)) != 0;
+                for (int q = l; q < len; q += G) cnt += (acol & (b_occ[b0 + q] >> 16)) != 0;
+            }
         }
     }
 #pragma unroll
     for (int d = G / 2; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, G);
+    if (prune) {
+        // hub rows of B (4 700 tiles on webbase-1M): left to 8 lanes, one such A tile kept its wave busy for 590 trips and
+        // the kernel waited for it (80 us, 60 of them this tail); the wave takes them together, 64 tiles per trip
+        const int lane = threadIdx.x & 63;
+        unsigned long long todo = __ballot(in && l == 0 && len >= LONG);
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int hb0 = __shfl(b0, src, 64), hlen = __shfl(len, src, 64);
+            const unsigned hcol = (unsigned)__shfl((int)acol, src, 64);
+            int c = 0;
+#pragma unroll 4
+            for (int q = lane; q < hlen; q += 64) c += (hcol & (b_occ[hb0 + q] >> 16)) != 0;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+            if ((lane & ~(G - 1)) == src) cnt = c;   // every lane of the tile's group holds its count
+        }
+    }
     if (!prune) cnt = len;
     if (in && l == 0) {
         aprod[arel] = len;
