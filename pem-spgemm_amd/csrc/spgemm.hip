@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(256) s1_reset_kernel(int *__restrict__ flags, 
 
 __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int mt,
                                                           const int *__restrict__ row_n, const int *__restrict__ row_lbase, int cap3,
-                                                          int qcap, int xlcap, int *__restrict__ row_list,
+                                                          int qcap, int xlcap, int rcap2, int qcap2, int *__restrict__ row_list,
                                                           int *__restrict__ bin_count, int *__restrict__ xl_base, int *__restrict__ row_tc,
                                                           long long *__restrict__ scalars)
 {
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
     int bin = nl == 0 ? -1 : (n > qcap || nl > xlcap) ? 4 : nl <= S1_CAP0 ? 0 : nl <= S1_CAP1 ? 1 : nl <= S1_CAP2 ? 2 : nl <= cap3 ? 3 : 4;
     if (bin == 0 && R > S1_RCAP0) bin = 1;
     if (bin == 1 && R > S1_RCAP1) bin = 2;
-    if (bin == 2 && R > S1_RCAP2) bin = 4;
+    if (bin == 2 && (R > rcap2 || n > qcap2)) bin = 4;
     if (bin == 3 && R > S1_RCAP3) bin = 4;
     // slots by ballot + prefix popcount inside a wave, one LDS atomic per wave and bin inside the block, ONE global
     // atomic per block and bin (order inside a bin is irrelevant): 4 k wave-level atomics on four counters serialised
@@ -417,9 +417,10 @@ __device__ __forceinline__ void s1_bitonic_regs(KeyT (&v)[EPT], KeyT *lds, const
     __syncthreads();
 }
 
-template <typename KeyT, int CAP, int QB, int THREADS, int RCAP>
+template <typename KeyT, int CAP, int QB, int THREADS, int RCAP, bool RANK = false>
 struct S1Row {
     KeyT *keys;
+    uint16_t *qmap;                // RANK: product index of the key at every live position (the key carries the position)
     const int *roff, *rbs;
     const unsigned *rco;           // occupied columns of every A tile of the row (pruning)
     const int *cstart;             // A tile holding product 64*c, for every 64th product (rows of up to 32768 products)
@@ -457,6 +458,7 @@ struct S1Row {
         const Product pr = tile_b(q, prune != 0);
         const int2 co = b_colocc[pr.b];
         if (prune && !(pr.acol & ((unsigned)co.y >> 16))) return ~KeyT(0);
+        if constexpr (RANK) return KeyT(co.x) << QB;        // the low bits take the key's live position (expand_compact)
         return (KeyT(co.x) << QB) | KeyT(q);
     }
     // expand all n products of the row, keep the live ones: their keys are packed into keys[0..nlive) in
@@ -497,7 +499,18 @@ struct S1Row {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int base = total + __shfl(inc - c, u * WAVES + wave, 64);
-                    if (key[u] != ~KeyT(0)) keys[base + __popcll(bal[u] & lt)] = key[u];
+                    if (key[u] != ~KeyT(0)) {
+                        const int pos = base + __popcll(bal[u] & lt);
+                        if constexpr (RANK) {
+                            // RANK keys: (tile column, live position).  Product order = position order, so the stable sort on
+                            // the column bits still yields ascending k inside a C tile; the product index -- which needs up to
+                            // 16 bits and would push a 19-bit tile column past 32 -- waits in a 2-byte side table
+                            keys[pos] = key[u] | KeyT(pos);
+                            qmap[pos] = (uint16_t)(q0 + u * THREADS + tid);
+                        } else {
+                            keys[pos] = key[u];
+                        }
+                    }
                 }
                 total += trip_total;
                 __syncthreads();                                      // the counts are re-posted by the next trip
@@ -667,7 +680,7 @@ extern "C" void pem_debug_s1(unsigned long long *out32, int reset)
 #define S1_DBG_MARK(k)
 #endif
 
-template <typename KeyT, int CAP, int QB, int THREADS, int RCAP>
+template <typename KeyT, int CAP, int QB, int THREADS, int RCAP, bool RANK = false>
 __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || sizeof(KeyT) == 8 ? 4 : 8) : 1) s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr,
                                                              int tr_lo, int a_lo, const int *__restrict__ a_tile_colidx,
                                                              const int *__restrict__ acnt, const int *__restrict__ row_n, const int *__restrict__ row_lbase,
@@ -686,7 +699,9 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
     __shared__ unsigned rco[RCAP];     // occupied columns of that A tile
     __shared__ int wsum[THREADS / 64];
     __shared__ int s_cnt;
-    constexpr bool COARSE = S1Row<KeyT, CAP, QB, THREADS, RCAP>::COARSE_OK;
+    static_assert(!RANK || (THREADS == 1024 && CAP <= (1 << QB) && sizeof(KeyT) == 4), "rank keys: ordered compaction, position fits the low bits");
+    __shared__ uint16_t qmap[RANK ? CAP : 1];
+    constexpr bool COARSE = S1Row<KeyT, CAP, QB, THREADS, RCAP, RANK>::COARSE_OK;
     __shared__ int cstart[COARSE ? S1_COARSE : 1];
     __shared__ unsigned radix_hist[THREADS == 1024 ? (THREADS / 64) * 256 : 1];   // digit counters of the radix sort (16-wave bins)
     __shared__ int ordcnt[64];                                                   // live counts per (chunk, wave) of the ordered compaction
@@ -703,8 +718,9 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
         const unsigned long long dbg_row0 = dbg_t;
 #endif
         if (tid == 0) s_cnt = 0;
-        S1Row<KeyT, CAP, QB, THREADS, RCAP> row;
+        S1Row<KeyT, CAP, QB, THREADS, RCAP, RANK> row;
         row.keys = keys;
+        row.qmap = qmap;
         row.roff = roff;
         row.rbs = rbs;
         row.rco = rco;
@@ -792,6 +808,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
             if (valid) {
                 KeyT key = keys[s];
                 int q = (int)(key & KeyT((1u << QB) - 1u));
+                if constexpr (RANK) q = qmap[q];
                 j = (int)(key >> QB);
                 head = s == 0 || (int)(keys[s - 1] >> QB) != j;
                 const auto pr = row.tile_b(q, false);
@@ -1794,7 +1811,7 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
 }
 
 template <typename KeyT>
-static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int mt, int cap3, int prune)
+static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int mt, int cap3, int prune, bool rank2)
 {
     const pem_tiled *A = p->A, *B = p->B;
     int *rl = p->row_list.as<int>();
@@ -1842,7 +1859,19 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
     }
     if (counts[2] > 0) {
         bin_begin();
-        PEM_ROWSORT(2, 8192, QBITS, 1024, 2048, 1 << 20)
+        if (rank2) {
+            // B with 2^17 .. 2^19 tile columns (cage15: 322 179): the 8192-key bin sorts 32-bit (tile column, live position)
+            // keys -- 78 KB of LDS, two workgroups per CU -- instead of 64-bit (tile column, product index) keys at 106 KB
+            const int grid = counts[2];
+            PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<8192,rank>", (s1_rowsort_kernel<uint32_t, 8192, 13, 1024, 1024, true>), grid, 1024,
+                             rl + (size_t)2 * mt, counts[2], A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, A->tile_colidx.as<int>(),
+                             p->aprod_off.as<int>(), p->row_n.as<int>(), p->row_lbase.as<int>(), B->tile_rowptr.as<int>(),
+                             B->tile_colocc.as<int2>(), A->tile_occ.as<uint32_t>(), prune, p->pairs_a.as<int>(), p->pairs_b.as<int>(),
+                             p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->block_info.as<int2>(), p->c_tile_rowptr.as<int>(),
+                             13 + bits_for((uint64_t)B->tile_cols));
+        } else {
+            PEM_ROWSORT(2, 8192, QBITS, 1024, 2048, 1 << 20)
+        }
         bin_end();
     }
     if (counts[1] > 0) {
@@ -1874,6 +1903,10 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     const int cap3 = k32 ? S1_CAP3 : S1_CAP2;
     const int qcap = k32 ? (1 << 15) - 1 : (1 << 24) - 1;
     const int xlcap = p->opt_xlcap > 0 ? p->opt_xlcap : 0x7FFFFFFF;   // test hook: rows with more live products take the global path
+    // 2^17 < tile columns < 2^19: the 8192-key bin takes 32-bit (tile column, live position) keys (see launch_rowsorts); its
+    // product index lives in a 16-bit side table and its A-tile table is the smaller one
+    const bool rank2 = !k32 && !p->opt_key64 && B->tile_cols < (1 << 19);
+    const int rcap2 = rank2 ? 1024 : S1_RCAP2, qcap2 = rank2 ? 65535 : qcap;
     p->state = 0;
     p->pairs_ready = false;
     p->c_rowidx_valid = false;
@@ -1917,7 +1950,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     // per-row tile counts are accumulated in c_tile_rowptr and scanned in place afterwards
     if (mt > 0)
         PEM_LAUNCH(ctx, s1_rowclass_kernel, grid_for((size_t)mt, 256), 256, A->tile_rowptr.as<int>(), p->tr_lo, mt, p->row_n.as<int>(),
-                   p->row_lbase.as<int>(), cap3, qcap, xlcap, p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(),
+                   p->row_lbase.as<int>(), cap3, qcap, xlcap, rcap2, qcap2, p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(),
                    p->c_tile_rowptr.as<int>(), reinterpret_cast<long long *>(ctx->d_scalars));
     // one read-back: P, the bin populations and the product total of the oversized rows
     int64_t P = 0, Pall = 0;
@@ -1959,9 +1992,9 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->scratch_off.reserve(sizeof(int) * (n + 4)));
         PEM_TRY(p->block_info.reserve(sizeof(int2) * (n / 256 + 4)));
         if (k32)
-            launch_rowsorts<uint32_t>(ctx, p, counts, mt, cap3, prune);
+            launch_rowsorts<uint32_t>(ctx, p, counts, mt, cap3, prune, false);
         else
-            launch_rowsorts<uint64_t>(ctx, p, counts, mt, cap3, prune);
+            launch_rowsorts<uint64_t>(ctx, p, counts, mt, cap3, prune, rank2);
         if (n_xl > 0) {   // oversized rows: global expand + stable radix sort on (row, tile col)
             PEM_TRY(p->prod_a.reserve(sizeof(int) * n_xl));
             PEM_TRY(p->prod_b.reserve(sizeof(int) * n_xl));
