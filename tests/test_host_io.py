@@ -141,3 +141,22 @@ def test_mm_reader_sweep_against_scipy(hostio, oracle, tmp_path, seed):
         G.sort_indices()
         assert G.nnz == want.nnz and np.array_equal(G.indptr, want.indptr) and np.array_equal(G.indices, want.indices)
         assert np.array_equal(G.data, want.data), (field, symm)
+
+
+def test_bench_data_dir_uses_the_real_file_when_present(pkg, standins, tmp_path):
+    """bench.py --data DIR: DIR/<workload>.mtx is read through pem_mm_read and reported as "real"; without the file the
+    seeded stand-in is used (real SuiteSparse files are not in the container)."""
+    import argparse
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rows, cols, I, J, V = standins.make("scircuit", 0.002)
+    standins.write_mtx(str(tmp_path / "scircuit.mtx"), rows, cols, I, J, V)
+    args = argparse.Namespace(data=str(tmp_path), workload="scircuit", scale=0.002)
+    r, c, i2, j2, v2, source, _ = bench.produce_input(args)
+    assert source == "real" and (r, c, len(i2)) == (rows, cols, len(I))
+    assert np.array_equal(i2, I) and np.array_equal(j2, J) and np.array_equal(v2, V)      # file order, exact doubles
+    args = argparse.Namespace(data=str(tmp_path), workload="mc2depi", scale=0.002)        # no such file under DIR
+    assert bench.produce_input(args)[5] == "synthetic"
