@@ -1397,36 +1397,68 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
                 }
             }
         }
-        // DEEP (plans averaging two or more pairs per C tile: 3.1 on cage15-class inputs, 30+ where a band multiplies
-        // itself): four pairs per trip, their eight record gathers in flight together instead of four dependent round
-        // trips; the products are still added pair by pair in ascending order.  cage15 slice: 17.3 -> 14.7 ms.  Not for
-        // everyone: webbase-1M's tiles hold 1.08 pairs and the extra code costs it 10 % (3 % when guarded by a wave vote,
+        // DEEP: plans averaging two or more pairs per C tile (3.1 on cage15-class inputs, 30+ where a band multiplies itself).
+        // Not for everyone: webbase-1M's tiles hold 1.08 pairs and the extra code costs it 10 % (3 % when guarded by a wave vote,
         // which in turn loses cage15's gain).
-        for (; DEEP && p + 4 <= p1; p += 4) {
-            int a4[4], b4[4];
-            unsigned aw4[4], bw4[4];
+        if constexpr (DEEP) {
+            // Four pairs per trip, their eight record gathers in flight together; and one trip ahead, the NEXT four pairs' ids and
+            // value offsets: the step is bound by the latency of its dependent gathers (ids -> records / value offsets -> values;
+            // one vector-memory instruction per ~17 cycles and CU on a cage15 slice), and this takes two of the four round trips
+            // off a trip's chain (cage15 slice: 14.6 -> 13.0 ms).  Going further -- records a trip ahead too, all loads
+            // unconditional so that the in-order memory counter can leave the younger ones in flight -- costs registers
+            // (88-134 VGPRs, 3-5 waves per SIMD) and loses: 13.9-15.7 ms.  Pairs are still added in ascending order.
+            int a4[4], b4[4], av4[4], bv4[4];
+            if (p + 4 <= p1) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                a4[k] = pairs_a[p + k];
-                b4[k] = pairs_b[p + k];
+                for (int k = 0; k < 4; ++k) {
+                    a4[k] = pairs_a[p + k];
+                    b4[k] = pairs_b[p + k];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    av4[k] = a_nnz_ptr[a4[k]];
+                    bv4[k] = b_nnz_ptr[b4[k]];
+                }
             }
+            for (; p + 4 <= p1; p += 4) {
+                unsigned aw4[4], bw4[4];
+                int na4[4], nb4[4], nav4[4], nbv4[4];
+                const bool more = p + 8 <= p1;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                aw4[k] = a_rec[16 * (size_t)a4[k] + r];
-                bw4[k] = b_rec_t[16 * (size_t)b4[k] + c];
-            }
+                for (int k = 0; k < 4; ++k) {
+                    na4[k] = more ? pairs_a[p + 4 + k] : 0;
+                    nb4[k] = more ? pairs_b[p + 4 + k] : 0;
+                }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const unsigned am = aw4[k] & 0xFFFFu, bm = bw4[k] & 0xFFFFu;
-                unsigned m = am & bm;
-                if (!m) continue;
-                const VT *av = a_vals + a_nnz_ptr[a4[k]] + (aw4[k] >> 16);
-                const VT *bv = b_vals_t + b_nnz_ptr[b4[k]] + (bw4[k] >> 16);
-                while (m) {
-                    const int kk = __builtin_ctz(m);
-                    m &= m - 1;
-                    const unsigned below = (1u << kk) - 1u;
-                    acc = pem_fma(av[__popc(am & below)], bv[__popc(bm & below)], acc);
+                for (int k = 0; k < 4; ++k) {
+                    aw4[k] = a_rec[16 * (size_t)a4[k] + r];
+                    bw4[k] = b_rec_t[16 * (size_t)b4[k] + c];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    nav4[k] = more ? a_nnz_ptr[na4[k]] : 0;
+                    nbv4[k] = more ? b_nnz_ptr[nb4[k]] : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned am = aw4[k] & 0xFFFFu, bm = bw4[k] & 0xFFFFu;
+                    unsigned m = am & bm;
+                    if (!m) continue;
+                    const VT *av = a_vals + av4[k] + (aw4[k] >> 16);
+                    const VT *bv = b_vals_t + bv4[k] + (bw4[k] >> 16);
+                    while (m) {
+                        const int kk = __builtin_ctz(m);
+                        m &= m - 1;
+                        const unsigned below = (1u << kk) - 1u;
+                        acc = pem_fma(av[__popc(am & below)], bv[__popc(bm & below)], acc);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    a4[k] = na4[k];
+                    b4[k] = nb4[k];
+                    av4[k] = nav4[k];
+                    bv4[k] = nbv4[k];
                 }
             }
         }
