@@ -1071,16 +1071,23 @@ __global__ void __launch_bounds__(256) s3_accumulate_kernel(
 // ([dword q][lane]; a lane only ever reads what it wrote itself -- same wave, program order -- so no barrier is
 // needed) and C row r |= OR_{kk in A row r} B row kk iterates over A's nonzeros only.  Two rows share a dword
 // (w[q] = row 2q | row 2q+1 << 16, the natural uint16 layout).
-__device__ __forceinline__ void s2_pair_mask(const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks, const int a,
-                                             const int b, unsigned (*bl)[256], const int tid, unsigned (&cw)[8])
+struct S2Masks {
+    uint4 A0, A1, B0, B1;   // the 16 row masks of the A tile and of the B tile, two rows per dword
+};
+__device__ __forceinline__ S2Masks s2_load_masks(const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks, const int a, const int b)
 {
-    const uint4 A0 = *reinterpret_cast<const uint4 *>(a_masks + 16 * (size_t)a);
-    const uint4 A1 = *reinterpret_cast<const uint4 *>(a_masks + 16 * (size_t)a + 8);
-    const uint4 B0 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)b);
-    const uint4 B1 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)b + 8);
-    bl[0][tid] = B0.x; bl[1][tid] = B0.y; bl[2][tid] = B0.z; bl[3][tid] = B0.w;
-    bl[4][tid] = B1.x; bl[5][tid] = B1.y; bl[6][tid] = B1.z; bl[7][tid] = B1.w;
-    const unsigned aw[8] = {A0.x, A0.y, A0.z, A0.w, A1.x, A1.y, A1.z, A1.w};
+    S2Masks m;
+    m.A0 = *reinterpret_cast<const uint4 *>(a_masks + 16 * (size_t)a);
+    m.A1 = *reinterpret_cast<const uint4 *>(a_masks + 16 * (size_t)a + 8);
+    m.B0 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)b);
+    m.B1 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)b + 8);
+    return m;
+}
+__device__ __forceinline__ void s2_pair_mask(const S2Masks &m, unsigned (*bl)[256], const int tid, unsigned (&cw)[8])
+{
+    bl[0][tid] = m.B0.x; bl[1][tid] = m.B0.y; bl[2][tid] = m.B0.z; bl[3][tid] = m.B0.w;
+    bl[4][tid] = m.B1.x; bl[5][tid] = m.B1.y; bl[6][tid] = m.B1.z; bl[7][tid] = m.B1.w;
+    const unsigned aw[8] = {m.A0.x, m.A0.y, m.A0.z, m.A0.w, m.A1.x, m.A1.y, m.A1.z, m.A1.w};
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         unsigned am = aw[q];            // bits 0-15: row 2q, bits 16-31: row 2q+1
@@ -1186,7 +1193,31 @@ __global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ s
     const long long t = t_blk + tile_off;
     // the masks
     unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // natural layout: cw[q] = row 2q | row 2q+1 << 16
-    for (int p = p0; p < p1; ++p) s2_pair_mask(a_masks, b_masks, pairs_a[p], pairs_b[p], bl, tid, cw);
+    // the pair list is walked with the next pair's masks and the one after's ids already in flight: a lane's chain per pair
+    // is then one gather deep instead of two (tiles of a band times a band hold 30+ pairs)
+    if (p0 < p1) {
+        S2Masks cur = s2_load_masks(a_masks, b_masks, pairs_a[p0], pairs_b[p0]);
+        int na = 0, nb = 0;
+        if (p0 + 1 < p1) {
+            na = pairs_a[p0 + 1];
+            nb = pairs_b[p0 + 1];
+        }
+        for (int p = p0; p < p1; ++p) {
+            S2Masks nxt = cur;
+            int nna = 0, nnb = 0;
+            if (p + 1 < p1) {
+                nxt = s2_load_masks(a_masks, b_masks, na, nb);
+                if (p + 2 < p1) {
+                    nna = pairs_a[p + 2];
+                    nnb = pairs_b[p + 2];
+                }
+            }
+            s2_pair_mask(cur, bl, tid, cw);
+            cur = nxt;
+            na = nna;
+            nb = nnb;
+        }
+    }
     int nnz_t = 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) nnz_t += __popc(cw[q]);
