@@ -1342,6 +1342,9 @@ __global__ void __launch_bounds__(256) s2_crowptr_kernel(const uint32_t *__restr
 // the two operand values.  Pairs ascend in k-tile, bits ascend, one fma per product: the same
 // chain as the oracle.
 constexpr int S3_EPW = S3_CHUNK;   // C entries per wave
+constexpr int S3_STAGE_PAIRS = 32;   // DEEP: tile pairs whose records are staged in LDS per trip ...
+constexpr int S3_STAGE_MIN = 8;      // ... for tiles with at least this many pairs
+constexpr int S3_QDEPTH = 4;         // products a lane may queue before the wave gathers their values
 template <typename VT, bool DEEP>
 __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b, long long ntc,
@@ -1355,6 +1358,8 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     // the tile offsets -- three dependent gathers per wave -- before that), then walks the tiles 64 at a time:
     // their value offsets and pair ranges sit one per lane in registers, and the entry -> tile lookup is a 6-step
     // shuffle search with no memory traffic.
+    __shared__ unsigned s3_rec[DEEP ? 4 * S3_STAGE_PAIRS * 32 : 1];   // DEEP: per wave, the records of up to S3_STAGE_PAIRS tile pairs ...
+    __shared__ int s3_q[DEEP ? 4 * 3 * S3_QDEPTH * 64 : 1];          // ... and per lane, the products waiting for their values
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long eb = wave * S3_EPW;
@@ -1393,7 +1398,91 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
         const int a0 = __shfl(my_a0, ti, 64), b0 = __shfl(my_b0, ti, 64), av0 = __shfl(my_av0, ti, 64), bv0 = __shfl(my_bv0, ti, 64);
         // (every shuffle sits in front of the `continue`: a lane that has left cannot be read from)
         const int a1 = __shfl(my_a1, ti, 64), b1 = __shfl(my_b1, ti, 64), av1 = __shfl(my_av1, ti, 64), bv1 = __shfl(my_bv1, ti, 64);
-        if (!valid) continue;
+        bool done = false;
+        if constexpr (DEEP) {
+            // Tiles with many pairs (where a band multiplies itself: ~40 entries x ~40 pairs per C tile): every lane of the tile
+            // would walk the SAME pair list and gather the same two 64-byte records per pair -- the vector-memory instructions
+            // that bound the step.  For each such tile among the wave's entries the whole wave loads the pairs' ids and value
+            // offsets once (one lane per pair), stages the records in LDS 32 pairs at a time (half a load instruction per pair),
+            // and the tile's lanes read their row / column word from there; only the operand VALUES are still gathered per lane.
+            // The pairs are visited in the same ascending order, so the fma chain -- and every bit of the result -- is unchanged.
+            unsigned long long big = __ballot(valid && p1 - p0 >= S3_STAGE_MIN);
+            if (big) {
+                const int wv = threadIdx.x >> 6;
+                unsigned *rec = s3_rec + wv * (S3_STAGE_PAIRS * 32);
+                int *qa = s3_q + wv * (3 * S3_QDEPTH * 64) + lane, *qb = qa + S3_QDEPTH * 64;     // slot-major, lane-minor
+                unsigned *qm = (unsigned *)(qb + S3_QDEPTH * 64);
+                unsigned src = 0;
+                if (valid) src = c_rowcolidx[e];
+                const int sr = src >> 4, sc = src & 15;
+                VT sacc = VT(0);
+                int qn = 0;
+                // the products found in the staged records wait in a per-lane queue (value offsets + the two masks) and are
+                // summed, oldest first, when a lane's queue is full: the value gathers of ALL the wave's lanes then share
+                // instructions instead of running per tile and pair with a handful of lanes
+                auto flush = [&]() {
+#pragma unroll
+                    for (int q = 0; q < S3_QDEPTH; ++q) {
+                        if (q < qn) {
+                            const unsigned mw = qm[q * 64];
+                            const unsigned am = mw & 0xFFFFu, bm = mw >> 16;
+                            const VT *av = a_vals + qa[q * 64];
+                            const VT *bv = b_vals_t + qb[q * 64];
+                            unsigned mm = am & bm;
+                            while (mm) {
+                                const int kk = __builtin_ctz(mm);
+                                mm &= mm - 1;
+                                const unsigned below = (1u << kk) - 1u;
+                                sacc = pem_fma(av[__popc(am & below)], bv[__popc(bm & below)], sacc);
+                            }
+                        }
+                    }
+                    qn = 0;
+                };
+                while (big) {                                          // wave-uniform: one trip per staged tile
+                    const int leader = __builtin_ctzll(big);
+                    const int til = __shfl(ti, leader, 64), pbase = __shfl(p0, leader, 64), np = __shfl(p1, leader, 64) - pbase;
+                    const bool mine = valid && ti == til;
+                    big &= ~__ballot(mine);
+                    if (mine) done = true;
+                    for (int pc = 0; pc < np; pc += S3_STAGE_PAIRS) {
+                        const int m = np - pc < S3_STAGE_PAIRS ? np - pc : S3_STAGE_PAIRS;
+                        int pa = 0, pb = 0, pav = 0, pbv = 0;          // lane l < m holds pair pc + l
+                        if (lane < m) {
+                            pa = pairs_a[pbase + pc + lane];
+                            pb = pairs_b[pbase + pc + lane];
+                            pav = a_nnz_ptr[pa];
+                            pbv = b_nnz_ptr[pb];
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the previous trip's reads are done before the records change
+                        __builtin_amdgcn_wave_barrier();
+                        for (int idx = lane; idx < m * 32; idx += 64) {   // word idx: pair idx >> 5; A's 16 row words, then B's 16 column words
+                            const int k = idx >> 5, w = idx & 31;
+                            const int ka = __shfl(pa, k, 64), kb = __shfl(pb, k, 64);
+                            rec[idx] = w < 16 ? a_rec[16 * (size_t)ka + w] : b_rec_t[16 * (size_t)kb + (w - 16)];
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        for (int k = 0; k < m; ++k) {
+                            const unsigned aw = rec[k * 32 + sr], bw = rec[k * 32 + 16 + sc];
+                            const unsigned am = aw & 0xFFFFu, bm = bw & 0xFFFFu;
+                            const int kav = __builtin_amdgcn_readlane(pav, k), kbv = __builtin_amdgcn_readlane(pbv, k);
+                            if (mine && (am & bm)) {
+                                qa[qn * 64] = kav + (int)(aw >> 16);
+                                qb[qn * 64] = kbv + (int)(bw >> 16);
+                                qm[qn * 64] = am | (bm << 16);
+                                ++qn;
+                            }
+                            if (__ballot(qn == S3_QDEPTH)) flush();
+                        }
+                    }
+                }
+                flush();
+                if (done) c_vals[e] = sacc;
+            }
+        }
+        if (!valid || done) continue;
         const unsigned rc = c_rowcolidx[e];
         const int r = rc >> 4, c = rc & 15;
         VT acc = VT(0);
