@@ -200,6 +200,7 @@ struct pem_cplan {
     int a_lo = 0, a_hi = 0;            // A tile id range of the slice
     int state = 0;                     // 0 created, 1 step1 done, 2 step2 done, 3 step3 done
     int opt_prune = 1, opt_key64 = 0, opt_xlcap = 0;   // PEM_PRUNE / PEM_S1_FORCE_KEY64 / PEM_S1_XLCAP, latched at plan creation
+    int opt_band = 1;                                  // PEM_S3_BAND (0: many-pair tiles stay in the entry-per-lane kernel)
     int64_t ntiles_c = 0, npairs = 0, nnz_c = 0;
     pem::DevBuf c_tile_rowptr, c_tile_colidx;
     mutable pem::DevBuf c_tile_rowidx; // _C_tileRowIdx: on demand from c_tile_rowptr on the row-local path (no reader there)

@@ -1342,10 +1342,11 @@ __global__ void __launch_bounds__(256) s2_crowptr_kernel(const uint32_t *__restr
 // the two operand values.  Pairs ascend in k-tile, bits ascend, one fma per product: the same
 // chain as the oracle.
 constexpr int S3_EPW = S3_CHUNK;   // C entries per wave
-constexpr int S3_STAGE_PAIRS = 32;   // DEEP: tile pairs whose records are staged in LDS per trip ...
-constexpr int S3_STAGE_MIN = 8;      // ... for tiles with at least this many pairs
-constexpr int S3_QDEPTH = 4;         // products a lane may queue before the wave gathers their values
-template <typename VT, bool DEEP>
+constexpr int S3_BAND_MIN = 8;       // C tiles with at least this many pairs go to s3_band_kernel (deep plans)
+constexpr int S3_BAND_CH = 16;       // pairs whose records one wave stages in LDS at a time (multiple of 4, at most 64)
+constexpr int S3_BAND_RS = S3_BAND_CH + 4;   // row stride of the staged records (words): 16-byte aligned, rows on different banks
+constexpr int S3_BAND_H = 1;         // meeting pairs a lane sums per trip of the gather loop
+template <typename VT, bool DEEP, bool BAND = false>
 __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b, long long ntc,
     const int *__restrict__ c_tile_nnz_ptr, long long nnz_c, const uint8_t *__restrict__ c_rowcolidx, VT *__restrict__ c_vals,
@@ -1358,8 +1359,6 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     // the tile offsets -- three dependent gathers per wave -- before that), then walks the tiles 64 at a time:
     // their value offsets and pair ranges sit one per lane in registers, and the entry -> tile lookup is a 6-step
     // shuffle search with no memory traffic.
-    __shared__ unsigned s3_rec[DEEP ? 4 * S3_STAGE_PAIRS * 32 : 1];   // DEEP: per wave, the records of up to S3_STAGE_PAIRS tile pairs ...
-    __shared__ int s3_q[DEEP ? 4 * 3 * S3_QDEPTH * 64 : 1];          // ... and per lane, the products waiting for their values
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long long eb = wave * S3_EPW;
@@ -1398,91 +1397,8 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
         const int a0 = __shfl(my_a0, ti, 64), b0 = __shfl(my_b0, ti, 64), av0 = __shfl(my_av0, ti, 64), bv0 = __shfl(my_bv0, ti, 64);
         // (every shuffle sits in front of the `continue`: a lane that has left cannot be read from)
         const int a1 = __shfl(my_a1, ti, 64), b1 = __shfl(my_b1, ti, 64), av1 = __shfl(my_av1, ti, 64), bv1 = __shfl(my_bv1, ti, 64);
-        bool done = false;
-        if constexpr (DEEP) {
-            // Tiles with many pairs (where a band multiplies itself: ~40 entries x ~40 pairs per C tile): every lane of the tile
-            // would walk the SAME pair list and gather the same two 64-byte records per pair -- the vector-memory instructions
-            // that bound the step.  For each such tile among the wave's entries the whole wave loads the pairs' ids and value
-            // offsets once (one lane per pair), stages the records in LDS 32 pairs at a time (half a load instruction per pair),
-            // and the tile's lanes read their row / column word from there; only the operand VALUES are still gathered per lane.
-            // The pairs are visited in the same ascending order, so the fma chain -- and every bit of the result -- is unchanged.
-            unsigned long long big = __ballot(valid && p1 - p0 >= S3_STAGE_MIN);
-            if (big) {
-                const int wv = threadIdx.x >> 6;
-                unsigned *rec = s3_rec + wv * (S3_STAGE_PAIRS * 32);
-                int *qa = s3_q + wv * (3 * S3_QDEPTH * 64) + lane, *qb = qa + S3_QDEPTH * 64;     // slot-major, lane-minor
-                unsigned *qm = (unsigned *)(qb + S3_QDEPTH * 64);
-                unsigned src = 0;
-                if (valid) src = c_rowcolidx[e];
-                const int sr = src >> 4, sc = src & 15;
-                VT sacc = VT(0);
-                int qn = 0;
-                // the products found in the staged records wait in a per-lane queue (value offsets + the two masks) and are
-                // summed, oldest first, when a lane's queue is full: the value gathers of ALL the wave's lanes then share
-                // instructions instead of running per tile and pair with a handful of lanes
-                auto flush = [&]() {
-#pragma unroll
-                    for (int q = 0; q < S3_QDEPTH; ++q) {
-                        if (q < qn) {
-                            const unsigned mw = qm[q * 64];
-                            const unsigned am = mw & 0xFFFFu, bm = mw >> 16;
-                            const VT *av = a_vals + qa[q * 64];
-                            const VT *bv = b_vals_t + qb[q * 64];
-                            unsigned mm = am & bm;
-                            while (mm) {
-                                const int kk = __builtin_ctz(mm);
-                                mm &= mm - 1;
-                                const unsigned below = (1u << kk) - 1u;
-                                sacc = pem_fma(av[__popc(am & below)], bv[__popc(bm & below)], sacc);
-                            }
-                        }
-                    }
-                    qn = 0;
-                };
-                while (big) {                                          // wave-uniform: one trip per staged tile
-                    const int leader = __builtin_ctzll(big);
-                    const int til = __shfl(ti, leader, 64), pbase = __shfl(p0, leader, 64), np = __shfl(p1, leader, 64) - pbase;
-                    const bool mine = valid && ti == til;
-                    big &= ~__ballot(mine);
-                    if (mine) done = true;
-                    for (int pc = 0; pc < np; pc += S3_STAGE_PAIRS) {
-                        const int m = np - pc < S3_STAGE_PAIRS ? np - pc : S3_STAGE_PAIRS;
-                        int pa = 0, pb = 0, pav = 0, pbv = 0;          // lane l < m holds pair pc + l
-                        if (lane < m) {
-                            pa = pairs_a[pbase + pc + lane];
-                            pb = pairs_b[pbase + pc + lane];
-                            pav = a_nnz_ptr[pa];
-                            pbv = b_nnz_ptr[pb];
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the previous trip's reads are done before the records change
-                        __builtin_amdgcn_wave_barrier();
-                        for (int idx = lane; idx < m * 32; idx += 64) {   // word idx: pair idx >> 5; A's 16 row words, then B's 16 column words
-                            const int k = idx >> 5, w = idx & 31;
-                            const int ka = __shfl(pa, k, 64), kb = __shfl(pb, k, 64);
-                            rec[idx] = w < 16 ? a_rec[16 * (size_t)ka + w] : b_rec_t[16 * (size_t)kb + (w - 16)];
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        for (int k = 0; k < m; ++k) {
-                            const unsigned aw = rec[k * 32 + sr], bw = rec[k * 32 + 16 + sc];
-                            const unsigned am = aw & 0xFFFFu, bm = bw & 0xFFFFu;
-                            const int kav = __builtin_amdgcn_readlane(pav, k), kbv = __builtin_amdgcn_readlane(pbv, k);
-                            if (mine && (am & bm)) {
-                                qa[qn * 64] = kav + (int)(aw >> 16);
-                                qb[qn * 64] = kbv + (int)(bw >> 16);
-                                qm[qn * 64] = am | (bm << 16);
-                                ++qn;
-                            }
-                            if (__ballot(qn == S3_QDEPTH)) flush();
-                        }
-                    }
-                }
-                flush();
-                if (done) c_vals[e] = sacc;
-            }
-        }
-        if (!valid || done) continue;
+        if (!valid) continue;
+        if (BAND && p1 - p0 >= S3_BAND_MIN) continue;   // many-pair tiles: s3_band_kernel's
         const unsigned rc = c_rowcolidx[e];
         const int r = rc >> 4, c = rc & 15;
         VT acc = VT(0);
@@ -1604,6 +1520,131 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
         c_vals[e] = acc;
     }
         if (chunk_end >= e_hi) break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Step 3 for C tiles with many pairs (deep plans: where a band multiplies itself a C tile holds ~40 entries and ~35 pairs).
+// In the entry-per-lane kernel every lane of such a tile walks the SAME pair list and gathers the same two 64-byte records
+// per pair; that kernel is bound by vector-memory issue.  Here ONE WAVE takes one tile at a time: the pairs' ids and value
+// offsets are loaded once (one lane per pair), their records go to LDS transposed -- recA[row][pair], recB[col][pair] --
+// with half a load instruction per pair, and every lane (= one C entry) scans its row of A words against its column of B
+// words FOUR pairs per 16-byte LDS read.  Where the masks meet, the product waits in a per-lane queue (value offsets + the
+// two masks); when a queue fills, all lanes gather their operands together.  Products are queued and summed in ascending
+// pair order, so the fma chain -- and every bit of C -- equals the entry-per-lane kernel's.
+// Grid: one wave per 64 consecutive C tiles; the wave finds the many-pair tiles among them by ballot.
+// ------------------------------------------------------------------------------------------
+template <typename VT>
+__global__ void __launch_bounds__(256) s3_band_kernel(const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a,
+                                                      const int *__restrict__ pairs_b, long long ntc, const int *__restrict__ c_tile_nnz_ptr,
+                                                      const uint8_t *__restrict__ c_rowcolidx, VT *__restrict__ c_vals,
+                                                      const int *__restrict__ a_nnz_ptr, const VT *__restrict__ a_vals,
+                                                      const unsigned *__restrict__ a_rec, const int *__restrict__ b_nnz_ptr,
+                                                      const VT *__restrict__ b_vals_t, const unsigned *__restrict__ b_rec_t)
+{
+    __shared__ __attribute__((aligned(16))) unsigned s_rec[4][2 * 16 * S3_BAND_RS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long t = ((long long)blockIdx.x * 4 + wv) * 64 + lane;
+    int my_off = 0, my_off1 = 0, my_p0 = 0, my_p1 = 0;
+    if (t < ntc) {
+        my_off = c_tile_nnz_ptr[t];
+        my_off1 = c_tile_nnz_ptr[t + 1];
+        my_p0 = pairs_offset[t];
+        my_p1 = pairs_offset[t + 1];
+    }
+    unsigned long long big = __ballot(my_p1 - my_p0 >= S3_BAND_MIN);
+    unsigned *recA = s_rec[wv], *recB = recA + 16 * S3_BAND_RS;
+    const int w = lane & 31, half = lane >> 5;
+    while (big) {                                                   // wave-uniform: one trip per many-pair tile
+        const int L = __builtin_ctzll(big);
+        big &= big - 1;
+        const int e0 = __builtin_amdgcn_readlane(my_off, L), n = __builtin_amdgcn_readlane(my_off1, L) - e0;
+        const int pb = __builtin_amdgcn_readlane(my_p0, L), np = __builtin_amdgcn_readlane(my_p1, L) - pb;
+        for (int sub = 0; sub < n; sub += 64) {                     // a tile holds up to 256 entries: 64 per trip
+            const bool mine = sub + lane < n;
+            const int e = e0 + sub + lane;
+            unsigned src = 0;
+            if (mine) src = c_rowcolidx[e];
+            const unsigned *rowA = recA + (src >> 4) * S3_BAND_RS, *colB = recB + (src & 15) * S3_BAND_RS;
+            VT acc = VT(0);
+            for (int pcs = 0; pcs < np; pcs += S3_BAND_CH) {        // S3_BAND_CH pairs per stage: lane k holds pair pcs + k
+                const int M = np - pcs < S3_BAND_CH ? np - pcs : S3_BAND_CH, M4 = (M + 3) & ~3;
+                int ia = 0, ib = 0, oa = 0, ob = 0;
+                if (lane < M) {
+                    ia = pairs_a[pb + pcs + lane];
+                    ib = pairs_b[pb + pcs + lane];
+                    oa = a_nnz_ptr[ia];
+                    ob = b_nnz_ptr[ib];
+                }
+                // the stage's records: word w of pair k is A's row word (w < 16) or B's column word; lanes 0-31 take the even pairs,
+                // 32-63 the odd ones.  All the loads first, then the LDS writes: one round trip per stage.
+                unsigned v[S3_BAND_CH / 2];
+#pragma unroll
+                for (int i = 0; i < S3_BAND_CH / 2; ++i) {
+                    if (2 * i >= M4) break;                         // (wave-uniform)
+                    const int k = 2 * i + half;
+                    const int ka = __shfl(ia, k, 64), kb = __shfl(ib, k, 64);
+                    v[i] = 0;                                       // (pairs M .. M4-1 pad the last group of four with empty masks)
+                    if (k < M) v[i] = w < 16 ? a_rec[16 * (size_t)ka + w] : b_rec_t[16 * (size_t)kb + (w - 16)];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the previous stage's reads are done before the records change
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < S3_BAND_CH / 2; ++i) {
+                    if (2 * i >= M4) break;
+                    recA[w * S3_BAND_RS + 2 * i + half] = v[i];     // (w >= 16 lands in recB: the arrays are adjacent)
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // scan: which of the stage's pairs meet in this entry -- LDS and VALU only
+                unsigned long long hits = 0;
+                for (int k4 = 0; k4 < M4; k4 += 4) {
+                    const uint4 a4 = *reinterpret_cast<const uint4 *>(rowA + k4), b4 = *reinterpret_cast<const uint4 *>(colB + k4);
+                    const unsigned nib = ((a4.x & b4.x & 0xFFFFu) ? 1u : 0u) | ((a4.y & b4.y & 0xFFFFu) ? 2u : 0u) |
+                                         ((a4.z & b4.z & 0xFFFFu) ? 4u : 0u) | ((a4.w & b4.w & 0xFFFFu) ? 8u : 0u);
+                    hits |= (unsigned long long)nib << k4;
+                }
+                if (!mine) hits = 0;
+                // sum: S3_BAND_H meeting pairs per lane and trip, lowest pair first; the operand gathers of all lanes share instructions
+                while (__ballot(hits != 0)) {
+                    unsigned am[S3_BAND_H], bm[S3_BAND_H];
+                    const VT *av[S3_BAND_H], *bv[S3_BAND_H];
+                    VT va[S3_BAND_H], vb[S3_BAND_H];
+#pragma unroll
+                    for (int h = 0; h < S3_BAND_H; ++h) {
+                        const bool on = hits != 0;
+                        const int k = on ? __builtin_ctzll(hits) : 0;
+                        hits &= hits - 1;                           // (0 stays 0)
+                        const unsigned aw = rowA[k], bw = colB[k];
+                        const int kav = __shfl(oa, k, 64), kbv = __shfl(ob, k, 64);
+                        am[h] = on ? aw & 0xFFFFu : 0u;
+                        bm[h] = on ? bw & 0xFFFFu : 0u;
+                        av[h] = a_vals + kav + (aw >> 16);
+                        bv[h] = b_vals_t + kbv + (bw >> 16);
+                        const unsigned mm = am[h] & bm[h];
+                        const unsigned below = mm ? (1u << __builtin_ctz(mm)) - 1u : 0u;
+                        va[h] = mm ? av[h][__popc(am[h] & below)] : a_vals[0];
+                        vb[h] = mm ? bv[h][__popc(bm[h] & below)] : b_vals_t[0];
+                    }
+#pragma unroll
+                    for (int h = 0; h < S3_BAND_H; ++h) {
+                        unsigned mm = am[h] & bm[h];
+                        if (mm) {
+                            acc = pem_fma(va[h], vb[h], acc);
+                            mm &= mm - 1;
+                            while (mm) {
+                                const int kk = __builtin_ctz(mm);
+                                mm &= mm - 1;
+                                const unsigned below = (1u << kk) - 1u;
+                                acc = pem_fma(av[h][__popc(am[h] & below)], bv[h][__popc(bm[h] & below)], acc);
+                            }
+                        }
+                    }
+                }
+            }
+            if (mine) c_vals[e] = acc;
+        }
     }
 }
 
@@ -1850,6 +1891,8 @@ extern "C" pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const p
     p->opt_key64 = e && !strcmp(e, "1");
     e = getenv("PEM_S1_XLCAP");
     p->opt_xlcap = e ? atoi(e) : 0;
+    e = getenv("PEM_S3_BAND");
+    p->opt_band = !(e && !strcmp(e, "0"));
     *out = p;
     return PEM_OK;
 }
@@ -2347,9 +2390,21 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
                      (long long)p->nnz_c, p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),       \
                      A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                  \
                      p->s3_chunk_tile.as<int>())
+#define PEM_S3_WIDE3(VT, NAME)                                                                                                                 \
+    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, true, true>), grid_for(((size_t)p->nnz_c + S3_EPW - 1) / S3_EPW * 64, 256), 256, \
+                     p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),       \
+                     (long long)p->nnz_c, p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),       \
+                     A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                  \
+                     p->s3_chunk_tile.as<int>())
 #define PEM_S3_LAUNCH(VT)                                                                                                                      \
     do {                                                                                                                                       \
-        if (wide && deep)                                                                                                                      \
+        if (wide && deep && p->opt_band) {                                                                                                     \
+            PEM_S3_WIDE3(VT, "s3_accumulate_wide_kernel<" #VT ",deep,band>");                                                                  \
+            PEM_LAUNCH_NAMED(ctx, "s3_band_kernel<" #VT ">", (s3_band_kernel<VT>), grid_for(ntc, 256), 256, p->pairs_offset.as<int>(),         \
+                             p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),                          \
+                             p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),                    \
+                             A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>());         \
+        } else if (wide && deep)                                                                                                               \
             PEM_S3_WIDE(VT, true, "s3_accumulate_wide_kernel<" #VT ",deep>");                                                                  \
         else if (wide)                                                                                                                         \
             PEM_S3_WIDE(VT, false, "s3_accumulate_wide_kernel<" #VT ">");                                                                      \
@@ -2366,6 +2421,7 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_S3_LAUNCH(double);
 #undef PEM_S3_LAUNCH
 #undef PEM_S3_WIDE
+#undef PEM_S3_WIDE3
     if (!ctx->capturing) PEM_HIP(hipEventRecord(ctx->ev[5], st));
     p->state = 3;
     return PEM_OK;
