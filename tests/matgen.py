@@ -75,6 +75,13 @@ def cases():
     J = np.concatenate([np.arange(n), np.arange(n), rng.integers(0, n, 6000)])
     key = rng.permutation(np.unique(I.astype(np.int64) * n + J))
     out["hub_row_4000"] = (n, n, (key // n).astype(np.int32), (key % n).astype(np.int32), _vals(rng, len(key)), False)
+    # a band times itself (cage15-like): C tiles with 1..13 pairs and up to 256 entries -- step 3's many-pair kernel next to
+    # the entry-per-lane one, pair counts that are no multiple of four, tiles of more than 64 entries
+    n = 1500
+    I = np.repeat(np.arange(n), 12)
+    J = np.clip(I + rng.integers(-100, 101, len(I)), 0, n - 1)
+    key = rng.permutation(np.unique(I.astype(np.int64) * n + J))
+    out["band_1500"] = (n, n, (key // n).astype(np.int32), (key % n).astype(np.int32), _vals(rng, len(key)), False)
     out.update(step1_cases(rng))
     return out
 

@@ -216,3 +216,36 @@ def test_options_are_latched_at_plan_creation(pkg, oracle, ctx, monkeypatch):
     plan2.spgemm()
     assert plan2.info()["npairs"] == op.npairs
 
+
+
+@pytest.mark.parametrize("name", ["band_1500", "blockrows_10000", "blockrows_1600"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_step3_many_pair_kernel_matches_entry_per_lane(pkg, oracle, ctx, monkeypatch, name, dtype):
+    """Deep plans send C tiles with 8 or more pairs to s3_band_kernel (records staged in LDS, one wave per tile) and the
+    rest to the entry-per-lane kernel; PEM_S3_BAND=0 keeps everything in the latter.  Both must give the oracle's values
+    bit for bit (same ascending-pair fma chain), and the band kernel must really have run."""
+    rows, cols, I, J, V, tr = CASES[name]
+    V = V.astype(dtype)
+    A = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V, False, dtype=dtype)
+    B = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V, True, dtype=dtype) if tr else A
+    f32 = dtype == np.float32
+    oa, ob = oracle.Csr(rows, cols, I, J, V.astype(np.float64), False), oracle.Csr(rows, cols, I, J, V.astype(np.float64), tr)
+    orp, oci, ov = oracle.csr_spgemm(oa, ob, 1, f32=f32).arrays()
+    got = {}
+    for band in ("1", "0"):
+        monkeypatch.setenv("PEM_S3_BAND", band)
+        plan = pkg.CPlan(ctx, A, B)
+        plan.spgemm()                                     # cold pass
+        ctx.set_kernel_profiling(True)
+        ctx.reset_kernel_stats()
+        plan.spgemm()                                     # warm pass
+        names = set(ctx.kernel_stats())
+        ctx.set_kernel_profiling(False)
+        info = plan.info()
+        assert info["npairs"] >= 2 * info["ntiles_c"], "not a deep plan: the case does not reach the kernel under test"
+        assert any(k.startswith("s3_band_kernel") for k in names) == (band == "1"), names
+        rp, ci, v = plan.export_csr()
+        assert np.array_equal(rp, orp) and np.array_equal(ci, oci)
+        assert v.dtype == dtype and np.array_equal(v.astype(np.float64), ov), f"{name} band={band}"
+        got[band] = plan.array("c_vals").copy()
+    assert np.array_equal(got["1"], got["0"])
