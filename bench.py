@@ -51,7 +51,7 @@ def kernel_alg_bytes(name, d):
         "s3_accumulate_wide_kernel": 8 * P + 8 * TC + NZ + (vb * nA + 68 * TA) + (vb * nB + 100 * TB) + vb * NZ,
     }
     if name.startswith("s3_accumulate"):            # value-typed kernels carry their template arguments in the name
-        name = name.split("<")[0]
+        name = name.split("<")[0].split("+")[0]     # (deep plans: the two step-3 launches count as one kernel)
     return table.get(name)
 
 
@@ -392,6 +392,14 @@ def main(argv=None):
                 ntiles_a=A.ntiles, ntiles_b=B.ntiles)
     kern = {k: dict(calls_per_step=v["calls"] / nprof, avg_ms=v["total_ms"] / max(v["calls"], 1), ms_per_step=v["total_ms"] / nprof)
             for k, v in stats.items()}
+    # deep plans run step 3 as TWO launches (many-pair tiles in s3_band_kernel, the rest in the entry-per-lane kernel): for the
+    # roofline they are one kernel -- B_alg is a whole product's bytes -- with the sum of the two durations
+    s3_pair = sorted(k for k in kern if k.startswith("s3_band_kernel") or k.endswith(",deep,band>"))
+    if len(s3_pair) == 2:
+        both = [kern.pop(k) for k in s3_pair]
+        kern["s3_accumulate_wide_kernel+s3_band_kernel" + s3_pair[1][s3_pair[1].index("<"):]] = dict(
+            calls_per_step=1.0, avg_ms=sum(b["avg_ms"] for b in both), ms_per_step=sum(b["ms_per_step"] for b in both),
+            parts={k: b["ms_per_step"] for k, b in zip(s3_pair, both)})
     dom = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
 
     # B_alg = compulsory CSR traffic of one product (this rank's slice at N>1)

@@ -16,12 +16,12 @@ for path in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), r
     with open(path) as f:
         for row in csv.DictReader(f):
             name = row.get("Kernel_Name", "")
-            short = name.split("(")[0].replace("pem::", "").replace("void ", "").replace(", false>", ">").replace(", true>", ",deep>")
+            short = name.split("(")[0].replace("pem::", "").replace("void ", "").replace(", false, false>", ">").replace(", true, false>", ",deep>").replace(", true, true>", ",deep,band>")
             per[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for path in glob.glob(os.path.join(out, "sq", "**", "*kernel_trace.csv"), recursive=True):
     with open(path) as f:
         for row in csv.DictReader(f):
-            short = row["Kernel_Name"].split("(")[0].replace("pem::", "").replace("void ", "").replace(", false>", ">").replace(", true>", ",deep>")
+            short = row["Kernel_Name"].split("(")[0].replace("pem::", "").replace("void ", "").replace(", false, false>", ">").replace(", true, false>", ",deep>").replace(", true, true>", ",deep,band>")
             dur[short].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
 cols = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_LDS",
         "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]
