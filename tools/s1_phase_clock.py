@@ -25,7 +25,7 @@ lib.pem_debug_s1(buf, 0)
 ms = {}
 for k, v in ctx.kernel_stats().items():
     if "rowsort" in k:
-        ms[int(k.split("<")[1].split(">")[0])] = v["total_ms"] / v["calls"]
+        ms[int(k.split("<")[1].split(">")[0].split(",")[0])] = v["total_ms"] / v["calls"]
 names = ["stage", "expand", "sort", "emit"]
 for b, cap in enumerate([512, 2048, 8192, 32768]):
     v = [buf[b * 8 + k] for k in range(8)]
