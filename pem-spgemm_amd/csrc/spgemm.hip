@@ -1544,7 +1544,11 @@ __global__ void __launch_bounds__(256) s3_band_kernel(const int *__restrict__ pa
 {
     __shared__ __attribute__((aligned(16))) unsigned s_rec[4][2 * 16 * S3_BAND_RS];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long long t = ((long long)blockIdx.x * 4 + wv) * 64 + lane;
+    // Workgroups go to the eight XCDs round-robin; XCD x takes the x-th contiguous eighth of the C tiles (the grid is a multiple of
+    // eight blocks), so that each L2 holds the A and B records of ITS stretch of the band instead of all eight holding the same
+    // (too large) one: L2 hit rate 31 % -> see DESIGN.md
+    const unsigned vblock = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long long t = ((long long)vblock * 4 + wv) * 64 + lane;
     int my_off = 0, my_off1 = 0, my_p0 = 0, my_p1 = 0;
     if (t < ntc) {
         my_off = c_tile_nnz_ptr[t];
@@ -2400,7 +2404,7 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
     do {                                                                                                                                       \
         if (wide && deep && p->opt_band) {                                                                                                     \
             PEM_S3_WIDE3(VT, "s3_accumulate_wide_kernel<" #VT ",deep,band>");                                                                  \
-            PEM_LAUNCH_NAMED(ctx, "s3_band_kernel<" #VT ">", (s3_band_kernel<VT>), grid_for(ntc, 256), 256, p->pairs_offset.as<int>(),         \
+            PEM_LAUNCH_NAMED(ctx, "s3_band_kernel<" #VT ">", (s3_band_kernel<VT>), (grid_for(ntc, 256) + 7u) & ~7u, 256, p->pairs_offset.as<int>(),         \
                              p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),                          \
                              p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),                    \
                              A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>());         \
