@@ -321,11 +321,11 @@ def main(argv=None):
 
     for _ in range(args.warmup):
         step()
-    # every pass re-reading its sizes (PEM_NO_WARM=1): buffers re-used, three host round trips per pass
-    os.environ["PEM_NO_WARM"] = "1"
+    # every pass re-reading its sizes (PEM_OPT_WARM = 0): buffers re-used, three host round trips per pass
+    plan.set_option("warm", 0)
     step()
     readback_ms = ctx.timings()["spgemm_wall_ms"]
-    del os.environ["PEM_NO_WARM"]
+    plan.set_option("warm", 1)
     step()
     step()
     tm = ctx.timings()          # step1/2/3 spans of a repeat pass launched kernel by kernel (a replayed graph has no step events)
@@ -494,7 +494,7 @@ def main(argv=None):
                         "min_ms": min(per_pass), "mean_ms": sum(per_pass) / len(per_pass), "max_ms": max(per_pass), "min_value": gf(min(per_pass)),
                         "note": "cold = first pem_spgemm on a fresh plan (every device allocation + 3 size read-backs: the reference's "
                                 "per-iteration cost, spgemm.cu:1136-1341; cold_first also loads the code objects); readback = buffers "
-                                "re-used, sizes read back every pass (PEM_NO_WARM=1); stream = warm plan, plain launches; min/mean/max = "
+                                "re-used, sizes read back every pass (PEM_OPT_WARM = 0); stream = warm plan, plain launches; min/mean/max = "
                                 "the timed passes one by one (this rank)"},
             "cpu_baseline": cpu_baseline,
             "exchange": ({"error": exchange_error} if exchange_error else None) if exchange_ms is None else {

@@ -54,6 +54,25 @@ pem_status pem_ctx_create_on_stream(int device, void *stream, pem_ctx **out);
 pem_status pem_ctx_destroy(pem_ctx *ctx);
 pem_status pem_ctx_synchronize(pem_ctx *ctx);
 
+/* Device memory.  The reference sizes two rmm pools once (spgemm.cu:808-817) and takes the eleven per-iteration
+ * buffers of its timed loop from a pool (cudaMallocAsync / cudaFreeAsync, spgemm.cu:1138-1295, 1118-1131).  Here every
+ * context owns an arena: the driver is asked for memory in few large slabs, all buffers of the context's tilings, plans
+ * and temporaries are carved out of them, and memory a destroyed handle gives back stays in the arena for the next one.
+ * A pass on a new plan therefore makes at most one driver allocation per sizing phase (pairs / C tiles / C entries) and
+ * none at all once the arena holds enough.  pem_ctx_reserve sizes the arena ahead of time (one driver allocation of
+ * `bytes`, skipped if a free block that large exists); pem_ctx_trim returns wholly free slabs to the driver. */
+pem_status pem_ctx_reserve(pem_ctx *ctx, int64_t bytes);
+pem_status pem_ctx_trim(pem_ctx *ctx);
+typedef struct {
+    int64_t slab_bytes;         /* held from the driver                         */
+    int64_t in_use_bytes;       /* handed out to live buffers                   */
+    int64_t peak_in_use_bytes;
+    int64_t largest_free_bytes; /* largest request served without the driver    */
+    int64_t driver_allocs;      /* hipMalloc calls so far                       */
+    int64_t block_allocs;       /* buffers carved so far                        */
+} pem_memory_stats;
+pem_status pem_ctx_memory_stats(pem_ctx *ctx, pem_memory_stats *out);
+
 /* ---- a2-a7: COO / CSR -> tiled CSR ---------------------------------------------------- */
 /* Replaces spgemm.cu:832-1066 (decide_which_tile, thrust sort/unique/reduce_by_key/scan,
  * COO->CSR, generate_tiles_csr, __transpose_B_mask, tile-level CSR/CSC + _B_tileOffsets).
@@ -136,11 +155,29 @@ pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const pem_tiled *B
                             int32_t tile_row_begin, int32_t tile_row_end, pem_cplan **out);
 pem_status pem_cplan_destroy(pem_ctx *ctx, pem_cplan *plan);
 
+/* Kernel variants and test hooks of a plan.  A new plan takes its defaults from the environment once, in
+ * pem_cplan_create (PEM_PRUNE=0, PEM_STEP1=esc, PEM_WIDE=0, PEM_NO_WARM=1, PEM_S3_BAND=0, PEM_S1_FORCE_KEY64=1,
+ * PEM_S1_XLCAP=n, PEM_EXPORT=rows); after that only pem_cplan_set_option changes them -- no entry point reads the
+ * environment at call time.  Changing an option makes the next pass a full (size-reading) one. */
+typedef enum {
+    PEM_OPT_PRUNE = 0,              /* 1 (default): drop tile products whose tiles cannot meet; 0: the reference's lists      */
+    PEM_OPT_STEP1_GLOBAL_SORT = 1,  /* 0 (default): row-local LDS sorts; 1: global expand + radix sort (the oversized-row path) */
+    PEM_OPT_WIDE = 2,               /* 1 (default): fused step 2 + entry-per-lane step 3; 0: 16-lanes-per-tile baseline kernels */
+    PEM_OPT_WARM = 3,               /* 1 (default): repeat passes re-use the previous pass's sizes (device-verified); 0: read back */
+    PEM_OPT_S3_BAND = 4,            /* 1 (default): many-pair C tiles of deep plans go to the wave-per-tile kernel              */
+    PEM_OPT_S1_FORCE_KEY64 = 5,     /* test hook: 64-bit sort keys whatever B's width                                          */
+    PEM_OPT_S1_XLCAP = 6,           /* test hook: tile rows with more live products take the global path (0: off)              */
+    PEM_OPT_EXPORT_ROWS = 7,        /* 0 (default): balanced chunk export; 1: 16 lanes per tile row (A/B baseline)             */
+    PEM_OPT_S1_SERIAL = 8           /* diagnostic: step 1's row bins one after the other instead of concurrently               */
+} pem_option;
+pem_status pem_cplan_set_option(pem_cplan *plan, pem_option which, int64_t value);
+pem_status pem_cplan_get_option(const pem_cplan *plan, pem_option which, int64_t *value);
+
 /* step 1 (spgemm.cu:1141-1218: tile_spgemm_step1_*_spa_kernel or the NSPARSE symbolic
  * path): tile-level symbolic product -> C tile list sorted by (tile row, tile col).
  * By default products whose A tile's occupied columns miss the B tile's occupied rows are
  * dropped (they contribute nothing; the reference keeps them as empty pairs / empty C tiles).
- * The final C is identical; PEM_PRUNE=0 in the environment reproduces the reference's lists. */
+ * The final C is identical; PEM_OPT_PRUNE = 0 reproduces the reference's lists. */
 pem_status pem_spgemm_step1(pem_ctx *ctx, pem_cplan *plan);
 /* step 2 (spgemm.cu:1220-1309: search_pairs<0/1>, compute_CMasksAndOffsets,
  * compute_CrowColIdx): pair lists, C tile bitmasks, per-tile nnz, intra-tile CSR. */
@@ -218,6 +255,15 @@ pem_status pem_set_kernel_profiling(pem_ctx *ctx, int enabled);
 pem_status pem_reset_kernel_stats(pem_ctx *ctx);
 pem_status pem_kernel_stats_count(pem_ctx *ctx, int *n);
 pem_status pem_kernel_stats_get(pem_ctx *ctx, int idx, char *name, int name_cap, int64_t *calls, double *total_ms);
+
+/* ---- test hooks -------------------------------------------------------------------------- */
+/* The device exclusive scan (replaces thrust::exclusive_scan, spgemm.cu:1168, 1242, 1288, and NSPARSE/utils_cuda_scan.h)
+ * on a caller's array: out[0..n] = exclusive prefix sums, out[n] = *total.  regime 0: chosen by n like the hot path;
+ * 1: one block; 2: the single-launch chained scan (n <= 262144); 3: the three-launch scan.  in_place scans the device
+ * copy in place (as the hot path does); stall_ticket >= 0 makes that block of the chained scan stall for ~0.1 ms before
+ * it publishes, so every later block sits out a long wait. */
+pem_status pem_debug_scan_i32(pem_ctx *ctx, const int32_t *in, int64_t n, int regime, int in_place, int stall_ticket,
+                              int32_t *out, int64_t *total);
 
 #ifdef __cplusplus
 }

@@ -37,7 +37,11 @@ ABI_SYMBOLS = [
     "pem_kernel_stats_count", "pem_kernel_stats_get", "pem_tiled_save", "pem_tiled_load",
     "pem_tiled_from_coo_f32", "pem_tiled_from_coo_device_f32", "pem_tiled_from_csr_f32", "pem_c_export_csr_f32",
     "pem_c_export_csr_device_f32", "pem_c_export_coo_f32", "pem_set_graph_replay",
+    "pem_ctx_reserve", "pem_ctx_trim", "pem_ctx_memory_stats", "pem_cplan_set_option", "pem_cplan_get_option", "pem_debug_scan_i32",
 ]
+
+# enum pem_option (include/pem_spgemm.h): kernel variants / test hooks of a plan
+OPTIONS = dict(prune=0, step1_global_sort=1, wide=2, warm=3, s3_band=4, s1_force_key64=5, s1_xlcap=6, export_rows=7, s1_serial=8)
 
 
 class PemError(RuntimeError):
@@ -65,6 +69,11 @@ class CacheKey(C.Structure):
     def of_file(cls, path, transpose=False):
         st = os.stat(path)
         return cls(st.st_size, st.st_mtime_ns, int(bool(transpose)), 0)
+
+
+class MemoryStats(C.Structure):
+    _fields_ = [("slab_bytes", C.c_int64), ("in_use_bytes", C.c_int64), ("peak_in_use_bytes", C.c_int64), ("largest_free_bytes", C.c_int64),
+                ("driver_allocs", C.c_int64), ("block_allocs", C.c_int64)]
 
 
 class Timings(C.Structure):
@@ -120,6 +129,29 @@ class Context:
         t = Timings()
         _check(lib().pem_get_timings(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in Timings._fields_}
+
+    def reserve(self, nbytes):
+        """size the context's device memory arena ahead of time (one driver allocation; the reference sizes its rmm pools
+        once, spgemm.cu:808-817)"""
+        _check(lib().pem_ctx_reserve(self._h, C.c_int64(int(nbytes))))
+
+    def trim(self):
+        """return wholly free slabs of the arena to the driver"""
+        _check(lib().pem_ctx_trim(self._h))
+
+    def memory_stats(self):
+        m = MemoryStats()
+        _check(lib().pem_ctx_memory_stats(self._h, C.byref(m)))
+        return {k: getattr(m, k) for k, _ in MemoryStats._fields_}
+
+    def debug_scan(self, values, regime=0, in_place=True, stall_ticket=-1):
+        """test hook: the device exclusive scan on a host array -> (prefix sums incl. the closing total, total)"""
+        v = np.ascontiguousarray(values, dtype=np.int32)
+        out = np.zeros(len(v) + 1, dtype=np.int32)
+        total = C.c_int64()
+        _check(lib().pem_debug_scan_i32(self._h, _p(v, C.c_int32), C.c_int64(len(v)), int(regime), int(bool(in_place)), int(stall_ticket),
+                                        _p(out, C.c_int32), C.byref(total)))
+        return out, total.value
 
     def set_graph_replay(self, on):
         """repeat passes of CPlan.spgemm() replayed as one hipGraph (no per-step timings for those passes)"""
@@ -259,6 +291,15 @@ class CPlan:
         self.ctx, self.A, self.B = ctx, A, B
         self._h = C.c_void_p()
         _check(lib().pem_cplan_create(ctx._h, A._h, B._h, int(tile_row_begin), int(tile_row_end), C.byref(self._h)))
+
+    def set_option(self, name, value):
+        """pem_cplan_set_option: kernel variants / test hooks (OPTIONS); the next pass is a full one"""
+        _check(lib().pem_cplan_set_option(self._h, OPTIONS[name], C.c_int64(int(value))))
+
+    def get_option(self, name):
+        v = C.c_int64()
+        _check(lib().pem_cplan_get_option(self._h, OPTIONS[name], C.byref(v)))
+        return v.value
 
     def step1(self):
         _check(lib().pem_spgemm_step1(self.ctx._h, self._h))

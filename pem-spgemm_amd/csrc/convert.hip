@@ -275,6 +275,7 @@ extern "C" pem_status pem_ctx_create_on_stream(int device, void *stream, pem_ctx
     PEM_HIP(hipSetDevice(device));
     pem_ctx *ctx = new pem_ctx();
     ctx->device = device;
+    ctx->arena = std::make_shared<pem::Arena>(device);
     if (stream) {
         ctx->stream = reinterpret_cast<hipStream_t>(stream);
     } else {
@@ -333,6 +334,35 @@ extern "C" pem_status pem_ctx_synchronize(pem_ctx *ctx)
     return PEM_OK;
 }
 
+extern "C" pem_status pem_ctx_reserve(pem_ctx *ctx, int64_t bytes)
+{
+    if (!ctx || bytes < 0) return PEM_E_INVALID;
+    PEM_ENTER(ctx);
+    return bytes ? ctx->arena->reserve((size_t)bytes) : PEM_OK;
+}
+
+extern "C" pem_status pem_ctx_trim(pem_ctx *ctx)
+{
+    if (!ctx) return PEM_E_INVALID;
+    PEM_ENTER(ctx);
+    PEM_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->arena->trim();
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_ctx_memory_stats(pem_ctx *ctx, pem_memory_stats *out)
+{
+    if (!ctx || !out) return PEM_E_INVALID;
+    const pem::Arena::Stats s = ctx->arena->stats();
+    out->slab_bytes = (int64_t)s.slab_bytes;
+    out->in_use_bytes = (int64_t)s.in_use_bytes;
+    out->peak_in_use_bytes = (int64_t)s.peak_in_use_bytes;
+    out->largest_free_bytes = (int64_t)s.largest_free_bytes;
+    out->driver_allocs = s.driver_allocs;
+    out->block_allocs = s.block_allocs;
+    return PEM_OK;
+}
+
 extern "C" pem_status pem_get_timings(pem_ctx *ctx, pem_timings *t)
 {
     if (!ctx || !t) return PEM_E_INVALID;
@@ -380,6 +410,20 @@ extern "C" pem_status pem_kernel_stats_get(pem_ctx *ctx, int idx, char *name, in
 // ------------------------------------------------------------------------------------------
 // conversion driver
 // ------------------------------------------------------------------------------------------
+// sizing phase "tiles": every per-tile array of a tiling (and the small sort of its tile CSC) in one driver allocation
+static pem_status reserve_tile_arrays(pem_ctx *ctx, pem_tiled *T)
+{
+    const size_t nnz = (size_t)T->nnz, nt = (size_t)T->ntiles;
+    return arena_phase(ctx->arena,
+                       {{&T->masks, 32 * (nt + 1)}, {&T->masks_t, 32 * (nt + 1)}, {&T->rowptr, 16 * (nt + 1)}, {&T->tile_rec, 64 * (nt + 1)},
+                        {&T->tile_occ, 4 * (nt + 4)}, {&T->tile_colocc, 8 * (nt + 4)}, {&T->tile_rec_t, 64 * (nt + 1)},
+                        {&T->vals_t, (size_t)T->value_bytes * (nnz + 1)}, {&T->tile_rowptr, 4 * ((size_t)T->tile_rows + 4)},
+                        {&T->tile_colidx, 4 * (nt + 4)}, {&T->tile_colptr, 4 * ((size_t)T->tile_cols + 4)}, {&T->tile_rowidx, 4 * (nt + 4)},
+                        {&T->tile_offsets, 4 * (nt + 4)}, {&ctx->tmp[8], 8 * nt}, {&ctx->tmp[9], 8 * nt}, {&ctx->tmp[10], 4 * nt},
+                        {&ctx->tmp[11], 4 * nt}, {&T->tile_keys, 8 * (nt + 1)}, {&T->tile_nnz_ptr, 4 * (nt + 4)},
+                        {&T->vals, (size_t)T->value_bytes * (nnz + 1)}, {&T->rowcolidx, nnz + 16}, {&ctx->tmp[0], 4 * (nnz + 4)}});
+}
+
 // Everything that follows from the sorted tile payload (tile_keys, tile_nnz_ptr, rowcolidx, vals): masks, intra-tile
 // row pointers, transposed masks (a5/a6), the step-3 records, the column-major values and the tile-level CSR/CSC
 // indices (a7).  Shared by the conversion and by the cache loader.  headx = exclusive scan of the tile-head flags;
@@ -471,6 +515,7 @@ static pem_status build_tiled(pem_ctx *ctx, pem_tiled *T, DevBuf &k0, DevBuf &k1
     }
     T->ntiles = ntiles;
     const size_t nt = (size_t)ntiles;
+    PEM_TRY(reserve_tile_arrays(ctx, T));
     PEM_TRY(T->tile_keys.reserve(sizeof(long long) * (nt + 1)));
     PEM_TRY(T->tile_nnz_ptr.reserve(sizeof(int) * (nt + 4)));
     PEM_TRY(T->vals.reserve((size_t)T->value_bytes * (nnz + 1)));
@@ -498,7 +543,7 @@ static pem_status tiled_from_device(pem_ctx *ctx, int rows, int cols, int64_t nn
         return PEM_E_OVERFLOW;
     }
     *out = nullptr;
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     auto t0 = std::chrono::high_resolution_clock::now();
     pem_tiled *T = new pem_tiled();
     T->value_bytes = value_bytes;
@@ -513,6 +558,12 @@ static pem_status tiled_from_device(pem_ctx *ctx, int rows, int cols, int64_t nn
         DevBuf k0, k1, v0, v1;
         const size_t n = (size_t)nnz;
         s = zero_flags(ctx);
+        // sizing phase "entries": sort buffers, head flags and everything nnz-sized of the tiling in one driver allocation
+        if (s == PEM_OK)
+            s = arena_phase(ctx->arena, {{&k0, sizeof(uint64_t) * (n + 1)}, {&k1, sizeof(uint64_t) * (n + 1)}, {&v0, sizeof(uint32_t) * (n + 1)},
+                                         {&v1, sizeof(uint32_t) * (n + 1)}, {&ctx->tmp[0], sizeof(int) * (n + 4)},
+                                         {&T->vals, (size_t)value_bytes * (n + 1)}, {&T->vals_t, (size_t)value_bytes * (n + 1)},
+                                         {&T->rowcolidx, n + 16}, {&ctx->sort_hist, sizeof(int) * (256 * (n / 4096 + 1) + 4)}});
         if (s == PEM_OK) s = k0.reserve(sizeof(uint64_t) * (n + 1));
         if (s == PEM_OK) s = k1.reserve(sizeof(uint64_t) * (n + 1));
         if (s == PEM_OK) s = v0.reserve(sizeof(uint32_t) * (n + 1));
@@ -541,7 +592,7 @@ static pem_status from_coo_host(pem_ctx *ctx, int rows, int cols, int64_t nnz, c
                                 int value_bytes, int transpose, pem_tiled **out)
 {
     if (!ctx || nnz < 0 || (nnz > 0 && (!I || !J || !V))) return PEM_E_INVALID;
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     DevBuf dI, dJ, dV;
     const size_t n = (size_t)nnz;
     PEM_TRY(dI.reserve(sizeof(int) * (n + 1)));
@@ -568,7 +619,7 @@ static pem_status from_csr_host(pem_ctx *ctx, int rows, int cols, const int32_t 
         }
     const int64_t nnz = rowptr[rows];
     if (nnz > 0 && (!colidx || !V)) return PEM_E_INVALID;
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     DevBuf dR, dJ, dV;
     const size_t n = (size_t)nnz;
     PEM_TRY(dR.reserve(sizeof(int) * ((size_t)rows + 1)));
@@ -732,7 +783,7 @@ __global__ void cache_heads_kernel(const int *__restrict__ tile_nnz_ptr, long lo
 extern "C" pem_status pem_tiled_save(pem_ctx *ctx, const pem_tiled *T, const char *path, const pem_cache_key *key)
 {
     if (!ctx || !T || !path || !*path) return PEM_E_INVALID;
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     const CacheLayout L = cache_layout(T->nnz, T->ntiles, T->value_bytes);
     std::vector<unsigned char> buf(sizeof(CacheHeader) + L.total, 0);
     unsigned char *payload = buf.data() + sizeof(CacheHeader);
@@ -835,7 +886,7 @@ extern "C" pem_status pem_tiled_load(pem_ctx *ctx, const char *path, const pem_c
     if (hash64(payload.data(), L.total, 0x70656D74696C6531ull) != h.payload_hash) return fail("payload checksum mismatch");
     lap("checksum");
 
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     hipStream_t st = ctx->stream;
     pem_tiled *T = new pem_tiled();
     T->value_bytes = (int)h.value_bytes;
@@ -849,6 +900,7 @@ extern "C" pem_status pem_tiled_load(pem_ctx *ctx, const char *path, const pem_c
     const size_t nt = (size_t)h.ntiles, nnz = (size_t)h.nnz;
     auto body = [&]() -> pem_status {
         PEM_TRY(zero_flags(ctx));
+        PEM_TRY(reserve_tile_arrays(ctx, T));
         PEM_TRY(T->tile_keys.reserve(sizeof(long long) * (nt + 1)));
         PEM_TRY(T->tile_nnz_ptr.reserve(sizeof(int) * (nt + 4)));
         PEM_TRY(T->vals.reserve((size_t)T->value_bytes * (nnz + 1)));
@@ -945,7 +997,7 @@ extern "C" pem_status pem_tiled_get_array(pem_ctx *ctx, const pem_tiled *t, pem_
         return PEM_E_INVALID;
     }
     if (want == 0) return PEM_OK;
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     PEM_HIP(hipMemcpyAsync(host_dst, src, want, hipMemcpyDeviceToHost, ctx->stream));
     PEM_HIP(hipStreamSynchronize(ctx->stream));
     return PEM_OK;
@@ -958,7 +1010,7 @@ extern "C" pem_status pem_flop_count(pem_ctx *ctx, const pem_tiled *A, const pem
         set_error("pem_flop_count: A is %d x %d, B is %d x %d", A->rows, A->cols, B->rows, B->cols);
         return PEM_E_INVALID;
     }
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     const size_t n = 16 * (size_t)A->tile_cols;   // == 16 * B->tile_rows
     DevBuf &ca = ctx->tmp[0], &rb = ctx->tmp[1];
     PEM_TRY(ca.reserve(sizeof(int) * n + 16));

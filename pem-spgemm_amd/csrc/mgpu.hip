@@ -124,6 +124,10 @@ extern "C" pem_status pem_mgpu_gather_csr(pem_mgpu *m, pem_cplan *const *plans, 
 {
     if (!m || !plans || root < 0 || root >= m->n) return PEM_E_INVALID;
     const int n = m->n;
+    if (n > 1 && !m->comm[(size_t)root]) {
+        set_error("pem_mgpu_gather_csr: the communicators were aborted by an earlier failed exchange");
+        return PEM_E_STATE;
+    }
     std::vector<int64_t> nrows((size_t)n), nnz((size_t)n), row_off((size_t)n + 1), nnz_off((size_t)n + 1);
     for (int g = 0; g < n; ++g) {
         if (!plans[g]) return PEM_E_INVALID;
@@ -152,46 +156,81 @@ extern "C" pem_status pem_mgpu_gather_csr(pem_mgpu *m, pem_cplan *const *plans, 
     const size_t total = (size_t)nnz_off[(size_t)n];
     if (total && (!colidx || !vals)) return PEM_E_INVALID;
 
+    // buffers first (each from its own device's arena), so that the clock below times the exchange and not a first call's
+    // device allocations
+    {
+        PEM_HIP(hipSetDevice(m->dev[(size_t)root]));
+        ArenaBind bind(m->ctx[(size_t)root]->arena);
+        PEM_TRY(m->r_ci.reserve(sizeof(int32_t) * (total + 4)));
+        PEM_TRY(m->r_v.reserve(sizeof(double) * (total + 1)));
+    }
+    for (int g = 0; g < n; ++g) {
+        PEM_HIP(hipSetDevice(m->dev[(size_t)g]));
+        ArenaBind bind(m->ctx[(size_t)g]->arena);
+        PEM_TRY(m->s_rp[(size_t)g].reserve(sizeof(int32_t) * ((size_t)nrows[(size_t)g] + 4)));
+        if (g != root) {
+            PEM_TRY(m->s_ci[(size_t)g].reserve(sizeof(int32_t) * ((size_t)nnz[(size_t)g] + 4)));
+            PEM_TRY(m->s_v[(size_t)g].reserve(sizeof(double) * ((size_t)nnz[(size_t)g] + 1)));
+        }
+    }
     const auto t0 = std::chrono::high_resolution_clock::now();
-    PEM_HIP(hipSetDevice(m->dev[(size_t)root]));
-    PEM_TRY(m->r_ci.reserve(sizeof(int32_t) * (total + 4)));
-    PEM_TRY(m->r_v.reserve(sizeof(double) * (total + 1)));
     // every rank: tiled C slice -> CSR on its own device (the root writes its slice straight into the assembled arrays)
     for (int g = 0; g < n; ++g) {
         PEM_HIP(hipSetDevice(m->dev[(size_t)g]));
-        PEM_TRY(m->s_rp[(size_t)g].reserve(sizeof(int32_t) * ((size_t)nrows[(size_t)g] + 4)));
         int32_t *ci = nullptr;
         double *v = nullptr;
         if (g == root) {
             ci = m->r_ci.as<int32_t>() + nnz_off[(size_t)g];
             v = m->r_v.as<double>() + nnz_off[(size_t)g];
         } else {
-            PEM_TRY(m->s_ci[(size_t)g].reserve(sizeof(int32_t) * ((size_t)nnz[(size_t)g] + 4)));
-            PEM_TRY(m->s_v[(size_t)g].reserve(sizeof(double) * ((size_t)nnz[(size_t)g] + 1)));
             ci = m->s_ci[(size_t)g].as<int32_t>();
             v = m->s_v[(size_t)g].as<double>();
         }
         PEM_TRY(pem_c_export_csr_device(m->ctx[(size_t)g], plans[g], m->s_rp[(size_t)g].as<int32_t>(), ci, v));
     }
     for (int g = 0; g < n; ++g) PEM_TRY(pem_ctx_synchronize(m->ctx[(size_t)g]));   // the exports ran on the contexts' streams
-    // one RCCL group: slice g -> its place in the root's arrays
+    // one RCCL group: slice g -> its place in the root's arrays.  Nothing returns from inside the group: the first failure is
+    // noted, the group is always closed, and a failed exchange aborts the communicators (an open or half-issued group
+    // leaves every later call on them -- ncclCommDestroy included -- undefined)
     if (n > 1) {
+        pem_status gs = PEM_OK;
+        auto nccl_ok = [&](ncclResult_t r, const char *what) {
+            if (r != ncclSuccess && gs == PEM_OK) {
+                set_error("pem_mgpu_gather_csr: %s -> %s", what, ncclGetErrorString(r));
+                gs = PEM_E_HIP;
+            }
+        };
+        auto hip_ok = [&](hipError_t e, const char *what) {
+            if (e != hipSuccess && gs == PEM_OK) {
+                set_error("pem_mgpu_gather_csr: %s -> %s", what, hipGetErrorString(e));
+                gs = PEM_E_HIP;
+            }
+        };
         PEM_NCCL(ncclGroupStart());
-        for (int g = 0; g < n; ++g) {
+        for (int g = 0; g < n && gs == PEM_OK; ++g) {
             if (g == root || nnz[(size_t)g] == 0) continue;
-            PEM_HIP(hipSetDevice(m->dev[(size_t)g]));
-            PEM_NCCL(ncclSend(m->s_ci[(size_t)g].p, (size_t)nnz[(size_t)g], ncclInt32, root, m->comm[(size_t)g], m->stream[(size_t)g]));
-            PEM_NCCL(ncclSend(m->s_v[(size_t)g].p, (size_t)nnz[(size_t)g], ncclFloat64, root, m->comm[(size_t)g], m->stream[(size_t)g]));
+            hip_ok(hipSetDevice(m->dev[(size_t)g]), "hipSetDevice(sender)");
+            if (gs != PEM_OK) break;
+            nccl_ok(ncclSend(m->s_ci[(size_t)g].p, (size_t)nnz[(size_t)g], ncclInt32, root, m->comm[(size_t)g], m->stream[(size_t)g]), "ncclSend(colidx)");
+            nccl_ok(ncclSend(m->s_v[(size_t)g].p, (size_t)nnz[(size_t)g], ncclFloat64, root, m->comm[(size_t)g], m->stream[(size_t)g]), "ncclSend(vals)");
         }
-        PEM_HIP(hipSetDevice(m->dev[(size_t)root]));
-        for (int g = 0; g < n; ++g) {
+        if (gs == PEM_OK) hip_ok(hipSetDevice(m->dev[(size_t)root]), "hipSetDevice(root)");
+        for (int g = 0; g < n && gs == PEM_OK; ++g) {
             if (g == root || nnz[(size_t)g] == 0) continue;
-            PEM_NCCL(ncclRecv(m->r_ci.as<int32_t>() + nnz_off[(size_t)g], (size_t)nnz[(size_t)g], ncclInt32, g, m->comm[(size_t)root],
-                              m->stream[(size_t)root]));
-            PEM_NCCL(ncclRecv(m->r_v.as<double>() + nnz_off[(size_t)g], (size_t)nnz[(size_t)g], ncclFloat64, g, m->comm[(size_t)root],
-                              m->stream[(size_t)root]));
+            nccl_ok(ncclRecv(m->r_ci.as<int32_t>() + nnz_off[(size_t)g], (size_t)nnz[(size_t)g], ncclInt32, g, m->comm[(size_t)root],
+                             m->stream[(size_t)root]), "ncclRecv(colidx)");
+            nccl_ok(ncclRecv(m->r_v.as<double>() + nnz_off[(size_t)g], (size_t)nnz[(size_t)g], ncclFloat64, g, m->comm[(size_t)root],
+                             m->stream[(size_t)root]), "ncclRecv(vals)");
         }
-        PEM_NCCL(ncclGroupEnd());
+        nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+        if (gs != PEM_OK) {
+            for (int g = 0; g < n; ++g)
+                if (m->comm[(size_t)g]) {
+                    (void)ncclCommAbort(m->comm[(size_t)g]);
+                    m->comm[(size_t)g] = nullptr;      // pem_mgpu_destroy skips it; the handle is dead for further gathers
+                }
+            return gs;
+        }
         for (int g = 0; g < n; ++g) {
             PEM_HIP(hipSetDevice(m->dev[(size_t)g]));
             PEM_HIP(hipStreamSynchronize(m->stream[(size_t)g]));

@@ -9,6 +9,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/pem_spgemm.h"
@@ -32,7 +36,69 @@ void set_error(const char *fmt, ...);
         if (_s != PEM_OK) return _s;      \
     } while (0)
 
-// Grow-only device buffer.  Contents are NOT preserved across a growth.
+// top of an ABI entry point that touches the device: the context's device is current and its arena bound
+#define PEM_ENTER(ctx)                        \
+    PEM_HIP(hipSetDevice((ctx)->device));     \
+    pem::ArenaBind _arena_bind((ctx)->arena)
+
+// ------------------------------------------------------------------------------------------
+// Device memory arena of one context.  Replaces the reference's rmm pool_memory_resource
+// (sized once, spgemm.cu:808-817) and the eleven cudaMallocAsync / cudaFreeAsync of every timed
+// iteration (spgemm.cu:1138-1295, 1118-1131): the driver is asked for memory in few large slabs
+// (hipMalloc clears and maps VRAM, milliseconds per GB), every buffer of the context's tilings,
+// plans and temporaries is carved out of them, and memory a handle gives back stays in the arena for
+// the next one -- so a fresh plan on a context that has run a product of the same size allocates
+// nothing, and a first plan allocates ONE slab sized from upper bounds (pem_cplan_create).
+// Ordering: a context is single-caller and all its device work is ordered on its stream (auxiliary
+// streams are joined before a pass ends), so a block freed by the host may be handed out again at
+// once: whatever still reads it was enqueued before whatever will write it.
+// ------------------------------------------------------------------------------------------
+class Arena {
+public:
+    explicit Arena(int device_) : device(device_) {}
+    ~Arena();
+    Arena(const Arena &) = delete;
+    Arena &operator=(const Arena &) = delete;
+    // 256-byte aligned block of at least `bytes`; nullptr when the driver refuses (pem::set_error is set)
+    void *alloc(size_t bytes);
+    void free(void *p);
+    // make sure ONE free block of at least `bytes` exists (at most one driver allocation)
+    pem_status reserve(size_t bytes);
+    // a sizing phase is about to carve buffers of these sizes: whatever part of them the free list cannot serve is
+    // obtained from the driver in ONE allocation
+    pem_status reserve_many(const size_t *sizes, int n);
+    // give wholly free slabs back to the driver
+    void trim();
+    struct Stats {
+        size_t slab_bytes, in_use_bytes, peak_in_use_bytes, largest_free_bytes;
+        long long driver_allocs, block_allocs;
+    };
+    Stats stats();
+    const int device;
+
+private:
+    struct Slab {
+        char *base;
+        size_t size;
+    };
+    void *take(size_t bytes);                  // from the free list, best fit; nullptr if none
+    pem_status add_slab(size_t bytes);
+    std::mutex mu;                             // handles may be destroyed by another thread than their context's
+    std::vector<Slab> slabs;
+    std::map<char *, size_t> free_blocks;      // by address, coalesced
+    std::map<char *, size_t> used_blocks;
+    size_t slab_bytes = 0, in_use = 0, peak = 0;
+    long long n_driver = 0, n_block = 0;
+};
+
+// the arena device buffers of the calling thread are taken from: bound by every ABI entry point (PEM_ENTER)
+std::shared_ptr<Arena> &current_arena();
+struct ArenaBind {
+    std::shared_ptr<Arena> prev;
+    explicit ArenaBind(const std::shared_ptr<Arena> &a) : prev(current_arena()) { current_arena() = a; }
+    ~ArenaBind() { current_arena() = prev; }
+};
+
 // bumped whenever any device buffer is (re)allocated or freed: a captured pass (hipGraph) bakes buffer addresses in
 inline std::atomic<unsigned long long> &alloc_generation()   // atomic: one host thread per device in multi-GPU runs
 {
@@ -40,39 +106,56 @@ inline std::atomic<unsigned long long> &alloc_generation()   // atomic: one host
     return gen;
 }
 
+// Grow-only device buffer carved out of the bound arena.  Contents are NOT preserved across a growth.
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    std::shared_ptr<Arena> arena;    // where p came from (keeps the slabs alive until the last buffer is gone)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap), arena(std::move(o.arena))
+    {
+        o.p = nullptr;
+        o.cap = 0;
+    }
     ~DevBuf() { release(); }
     void release()
     {
         if (p) {
-            (void)hipFree(p);
+            arena->free(p);
             ++alloc_generation();
         }
         p = nullptr;
         cap = 0;
+        arena.reset();
     }
     pem_status reserve(size_t bytes)
     {
         if (bytes <= cap) return PEM_OK;
         release();
+        const std::shared_ptr<Arena> &a = current_arena();
+        if (!a) {
+            set_error("internal: device buffer requested outside an ABI call (no arena bound)");
+            return PEM_E_INVALID;
+        }
         size_t want = (bytes + 255) & ~size_t(255);
         ++alloc_generation();
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {
-            p = nullptr;
-            set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
-            return PEM_E_NOMEM;
-        }
+        p = a->alloc(want);
+        if (!p) return PEM_E_NOMEM;
+        arena = a;
         cap = want;
         return PEM_OK;
     }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
+
+// One driver allocation per sizing phase of a first pass: the buffers listed are about to be grown to these sizes.
+struct PhaseWant {
+    const DevBuf *buf;
+    size_t bytes;
+};
+pem_status arena_phase(const std::shared_ptr<Arena> &arena, std::initializer_list<PhaseWant> wants);
 
 struct KernelStat {
     std::string name;
@@ -86,12 +169,13 @@ struct PendingSpan {
 };
 
 // device-side status words, zeroed at the start of every ABI call that launches kernels
-enum DevFlag { FLAG_RANGE = 0, FLAG_DUP = 1, FLAG_OVERFLOW = 2, FLAG_CAPACITY = 3, NUM_FLAGS = 8 };
+enum DevFlag { FLAG_RANGE = 0, FLAG_DUP = 1, FLAG_OVERFLOW = 2, FLAG_CAPACITY = 3, FLAG_INTERNAL = 4, NUM_FLAGS = 8 };
 
 }  // namespace pem
 
 struct pem_ctx {
     int device = 0;
+    std::shared_ptr<pem::Arena> arena;   // every device buffer of this context's handles and temporaries
     hipStream_t stream = nullptr;
     bool own_stream = false;
     // pinned host page for scalar read-backs (replaces the reference's racy pageable
@@ -107,6 +191,8 @@ struct pem_ctx {
     bool capturing = false;            // a warm pass is being captured into a hipGraph: no timing events, no syncs
     bool chain_events = false;         // pem_spgemm: steps run back to back, boundary events are shared
     pem::DevBuf tmp[12];               // step/convert temporaries, see call sites
+    int dbg_scan_force = 0;            // pem_debug_scan_i32: 0 automatic, 2 single-launch chained scan, 3 three-launch scan
+    int dbg_scan_stall_ticket = -1;    // ... and the chained scan's block that stalls before it publishes
     // timing
     hipEvent_t ev[8] = {};             // step spans
     // fork/join inside a step: an independent long-tailed kernel runs on an auxiliary stream
@@ -199,8 +285,10 @@ struct pem_cplan {
     int tr_lo = 0, tr_hi = 0;
     int a_lo = 0, a_hi = 0;            // A tile id range of the slice
     int state = 0;                     // 0 created, 1 step1 done, 2 step2 done, 3 step3 done
-    int opt_prune = 1, opt_key64 = 0, opt_xlcap = 0;   // PEM_PRUNE / PEM_S1_FORCE_KEY64 / PEM_S1_XLCAP, latched at plan creation
-    int opt_band = 1;                                  // PEM_S3_BAND (0: many-pair tiles stay in the entry-per-lane kernel)
+    // pem_option values (include/pem_spgemm.h); defaults come from the environment when the plan is created
+    int opt_prune = 1, opt_key64 = 0, opt_xlcap = 0;
+    int opt_band = 1;                                  // 0: many-pair tiles stay in the entry-per-lane kernel
+    int opt_step1_esc = 0, opt_wide = 1, opt_warm = 1, opt_export_rows = 0, opt_s1_serial = 0;
     int64_t ntiles_c = 0, npairs = 0, nnz_c = 0;
     pem::DevBuf c_tile_rowptr, c_tile_colidx;
     mutable pem::DevBuf c_tile_rowidx; // _C_tileRowIdx: on demand from c_tile_rowptr on the row-local path (no reader there)

@@ -3,6 +3,7 @@
 // reduce_by_key call sites (spgemm.cu:869-927, 990-1061, 1168, 1242, 1288) and the warp
 // scan of NSPARSE/utils_cuda_scan.h:19-35.  No thrust, no rocPRIM: plain HIP.
 #include "pem_internal.h"
+#include <algorithm>
 #include <cstdarg>
 
 namespace pem {
@@ -16,6 +17,175 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 const char *last_error() { return g_err; }
+
+// ------------------------------------------------------------------------------------------
+// device memory arena (pem_internal.h)
+// ------------------------------------------------------------------------------------------
+std::shared_ptr<Arena> &current_arena()
+{
+    static thread_local std::shared_ptr<Arena> a;
+    return a;
+}
+
+static constexpr size_t ARENA_ALIGN = 256;
+static constexpr size_t ARENA_MIN_SLAB = size_t(64) << 20;     // small requests share 64 MiB slabs
+static constexpr size_t ARENA_MAX_GROWTH = size_t(4) << 30;    // ... a slab is never padded by more than this
+
+Arena::~Arena()
+{
+    // the owners of every block hold a reference to the arena, so nothing is in use any more
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    for (auto &s : slabs) (void)hipFree(s.base);
+}
+
+pem_status Arena::add_slab(size_t bytes)
+{
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipMalloc(%zu bytes) failed: %s (arena holds %zu bytes, %zu in use)", bytes, hipGetErrorString(e), slab_bytes, in_use);
+        return PEM_E_NOMEM;
+    }
+    slabs.push_back(Slab{static_cast<char *>(p), bytes});
+    slab_bytes += bytes;
+    ++n_driver;
+    free_blocks[static_cast<char *>(p)] = bytes;
+    return PEM_OK;
+}
+
+void *Arena::take(size_t bytes)
+{
+    auto best = free_blocks.end();
+    for (auto it = free_blocks.begin(); it != free_blocks.end(); ++it)
+        if (it->second >= bytes && (best == free_blocks.end() || it->second < best->second)) best = it;
+    if (best == free_blocks.end()) return nullptr;
+    char *p = best->first;
+    const size_t have = best->second;
+    free_blocks.erase(best);
+    if (have > bytes) free_blocks[p + bytes] = have - bytes;
+    used_blocks[p] = bytes;
+    in_use += bytes;
+    if (in_use > peak) peak = in_use;
+    ++n_block;
+    return p;
+}
+
+void *Arena::alloc(size_t bytes)
+{
+    bytes = (bytes + ARENA_ALIGN - 1) & ~(ARENA_ALIGN - 1);
+    if (bytes == 0) bytes = ARENA_ALIGN;
+    std::lock_guard<std::mutex> lock(mu);
+    if (void *p = take(bytes)) return p;
+    // grow: the request itself, padded so that a run of growing requests (a first pass sizes its buffers one after the
+    // other) does not end up as one driver call each
+    size_t pad = slab_bytes / 2;
+    if (pad > ARENA_MAX_GROWTH) pad = ARENA_MAX_GROWTH;
+    size_t want = bytes + pad;
+    if (want < ARENA_MIN_SLAB) want = ARENA_MIN_SLAB;
+    if (add_slab(want) != PEM_OK) {
+        if (want == bytes || add_slab(bytes) != PEM_OK) return nullptr;   // retry without the padding
+    }
+    return take(bytes);
+}
+
+void Arena::free(void *vp)
+{
+    if (!vp) return;
+    char *p = static_cast<char *>(vp);
+    std::lock_guard<std::mutex> lock(mu);
+    auto u = used_blocks.find(p);
+    if (u == used_blocks.end()) return;   // not ours (cannot happen: DevBuf remembers its arena)
+    size_t bytes = u->second;
+    used_blocks.erase(u);
+    in_use -= bytes;
+    // coalesce with the neighbours -- but never across a slab boundary (slabs may happen to abut)
+    auto slab_of = [&](char *q) -> const Slab * {
+        for (auto &s : slabs)
+            if (q >= s.base && q < s.base + s.size) return &s;
+        return nullptr;
+    };
+    const Slab *sl = slab_of(p);
+    auto next = free_blocks.lower_bound(p);
+    if (next != free_blocks.end() && next->first == p + bytes && sl && next->first < sl->base + sl->size) {
+        bytes += next->second;
+        next = free_blocks.erase(next);
+    }
+    if (next != free_blocks.begin()) {
+        auto prev = std::prev(next);
+        if (prev->first + prev->second == p && sl && prev->first >= sl->base) {
+            prev->second += bytes;
+            return;
+        }
+    }
+    free_blocks[p] = bytes;
+}
+
+pem_status Arena::reserve(size_t bytes)
+{
+    bytes = (bytes + ARENA_ALIGN - 1) & ~(ARENA_ALIGN - 1);
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &f : free_blocks)
+        if (f.second >= bytes) return PEM_OK;
+    return add_slab(bytes);
+}
+
+pem_status Arena::reserve_many(const size_t *sizes, int n)
+{
+    std::lock_guard<std::mutex> lock(mu);
+    std::vector<size_t> want;
+    for (int i = 0; i < n; ++i)
+        if (sizes[i]) want.push_back((sizes[i] + ARENA_ALIGN - 1) & ~(ARENA_ALIGN - 1));
+    std::sort(want.begin(), want.end(), [](size_t a, size_t b) { return a > b; });
+    std::vector<size_t> avail;
+    for (auto &f : free_blocks) avail.push_back(f.second);
+    size_t missing = 0;
+    for (size_t w : want) {            // best fit over a copy of the free list, largest request first
+        long best = -1;
+        for (size_t i = 0; i < avail.size(); ++i)
+            if (avail[i] >= w && (best < 0 || avail[i] < avail[(size_t)best])) best = (long)i;
+        if (best >= 0)
+            avail[(size_t)best] -= w;
+        else
+            missing += w;
+    }
+    return missing ? add_slab(missing) : PEM_OK;
+}
+
+pem_status arena_phase(const std::shared_ptr<Arena> &arena, std::initializer_list<PhaseWant> wants)
+{
+    size_t sizes[32];
+    int n = 0;
+    for (auto &w : wants)
+        if (w.bytes > w.buf->cap && n < 32) sizes[n++] = w.bytes;
+    return n ? arena->reserve_many(sizes, n) : PEM_OK;
+}
+
+void Arena::trim()
+{
+    std::lock_guard<std::mutex> lock(mu);
+    for (size_t i = 0; i < slabs.size();) {
+        auto f = free_blocks.find(slabs[i].base);
+        if (f != free_blocks.end() && f->second == slabs[i].size) {
+            free_blocks.erase(f);
+            (void)hipFree(slabs[i].base);
+            slab_bytes -= slabs[i].size;
+            slabs.erase(slabs.begin() + (long)i);
+        } else {
+            ++i;
+        }
+    }
+}
+
+Arena::Stats Arena::stats()
+{
+    std::lock_guard<std::mutex> lock(mu);
+    size_t largest = 0;
+    for (auto &f : free_blocks)
+        if (f.second > largest) largest = f.second;
+    return Stats{slab_bytes, in_use, peak, largest, n_driver, n_block};
+}
 
 // ------------------------------------------------------------------------------------------
 // kernel spans
@@ -230,7 +400,7 @@ __global__ void __launch_bounds__(1024) scan_small_kernel(const int *in, int *ou
                                                           int *__restrict__ flags)
 {
     // eight items per thread and trip (two 16-byte loads): half the trips, and barriers, of a four-item loop
-    __shared__ int wsum[16];
+    __shared__ long long wsum[16];   // 64-bit sums: a total beyond int32 must be reported, not wrapped
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long long carry = 0;
     for (size_t base = 0; base < n; base += 8192) {
@@ -244,21 +414,21 @@ __global__ void __launch_bounds__(1024) scan_small_kernel(const int *in, int *ou
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = (i0 + k < n) ? in[i0 + k] : 0;
         }
-        int tsum = 0;
+        long long tsum = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) tsum += v[k];
-        const int inc = wave_inclusive_scan(tsum);
+        const long long inc = wave_inclusive_scan(tsum);
         if (lane == 63) wsum[wave] = inc;
         __syncthreads();
-        int woff = 0, btotal = 0;
+        long long woff = 0, btotal = 0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) {
-            const int c = wsum[w];
+            const long long c = wsum[w];
             if (w < wave) woff += c;
             btotal += c;
         }
         int o[8];
-        o[0] = (int)carry + woff + inc - tsum;
+        o[0] = (int)(carry + woff + inc - tsum);
 #pragma unroll
         for (int k = 1; k < 8; ++k) o[k] = o[k - 1] + v[k - 1];
         if (i0 + 8 <= n) {
@@ -280,20 +450,29 @@ __global__ void __launch_bounds__(1024) scan_small_kernel(const int *in, int *ou
 }
 
 // mid-size arrays (tile-row counts of a plan, 256-tile group counts): ONE launch of up to SCAN_MID_BLOCKS blocks.  Every
-// block scans its 2048 items, publishes its total, and sums the totals of all earlier blocks -- at most 127 words, two per
-// lane of one wave, read in one round trip.  So few blocks are all resident at once, so the wait is for blocks that are
-// already running; should one not have published within the poll budget (it never has), the block adds up the input in
-// front of it itself -- slow, never wrong, never a hang.  The last block to finish clears the words for the next scan.
-// A single 1024-thread block took 17 us for 62 k items and 35 us for 75 k (8192 items per trip, two barriers each).
+// block scans 2048 items, publishes its total, and sums the totals of all earlier blocks -- at most 127 words, two per
+// lane of one wave, read in one round trip.
+// Which 2048 items a block takes is decided by a TICKET (one atomic per block), not by blockIdx: HIP promises nothing
+// about dispatch order, and these scans run while row-sort workgroups from the auxiliary streams hold most of the CUs.
+// A block that holds ticket k only ever waits for tickets < k, and whoever drew those is already running and publishes
+// without waiting for anybody: the chain cannot deadlock whatever the order of dispatch.  in == out is allowed: a block
+// reads its own items before it writes them and nobody else reads them (there is no "re-sum the input" fallback any
+// more -- the one this kernel had was wrong for in-place scans).  Should the wait ever run out (it cannot, see above),
+// FLAG_INTERNAL makes the host fail the call instead of returning a wrong scan.  The last block to finish clears the
+// words for the next scan.  A single 1024-thread block took 17 us for 62 k items and 35 us for 75 k.
 constexpr int SCAN_MID_ITEMS = 2048, SCAN_MID_BLOCKS = 128;
 constexpr unsigned long long SCAN_MID_VALID = 1ull << 63;
 
-__global__ void __launch_bounds__(256) scan_mid_kernel(const int *in, int *out, size_t n, unsigned long long *state, int *done,
-                                                       long long *__restrict__ total64, int *__restrict__ flags)
+__global__ void __launch_bounds__(256) scan_mid_kernel(const int *in, int *out, size_t n, unsigned long long *state, int *ctl /* done, ticket */,
+                                                       long long *__restrict__ total64, int *__restrict__ flags, int stall_ticket)
 {
-    __shared__ int wsum[4];
+    __shared__ long long wsum[4];
     __shared__ long long s_excl;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x, nblk = gridDim.x;
+    __shared__ int s_ticket;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nblk = gridDim.x;
+    if (tid == 0) s_ticket = atomicAdd(&ctl[1], 1);
+    __syncthreads();
+    const int blk = s_ticket;
     const size_t i0 = (size_t)blk * SCAN_MID_ITEMS + (size_t)tid * 8;
     int v[8];
     if (i0 + 8 <= n) {
@@ -304,43 +483,42 @@ __global__ void __launch_bounds__(256) scan_mid_kernel(const int *in, int *out, 
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = (i0 + k < n) ? in[i0 + k] : 0;
     }
-    int tsum = 0;
+    long long tsum = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) tsum += v[k];
-    const int inc = wave_inclusive_scan(tsum);
+    const long long inc = wave_inclusive_scan(tsum);
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    int woff = 0, btotal = 0;
+    long long woff = 0, btotal = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
         if (w < wave) woff += wsum[w];
         btotal += wsum[w];
     }
     if (wave == 0) {
-        if (lane == 0) __hip_atomic_store(&state[blk], SCAN_MID_VALID | (unsigned long long)(unsigned)btotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blk == stall_ticket)                    // test hook: every later ticket has to sit out a long wait
+            for (int k = 0; k < 50; ++k) __builtin_amdgcn_s_sleep(127);   // ~0.2 ms
+        // (62 bits of total: the block's own sum can exceed 2^31 when the scan as a whole overflows -- flagged below)
+        if (lane == 0) __hip_atomic_store(&state[blk], SCAN_MID_VALID | (unsigned long long)btotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         long long excl = 0;
         bool ok = false;
-        for (int polls = 0; polls < (1 << 16) && !ok; ++polls) {
+        for (long long polls = 0; polls < (1ll << 24) && !ok; ++polls) {
             const unsigned long long a = lane < blk ? __hip_atomic_load(&state[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SCAN_MID_VALID;
             const unsigned long long b = 64 + lane < blk ? __hip_atomic_load(&state[64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SCAN_MID_VALID;
             if (__ballot(!(a & SCAN_MID_VALID) || !(b & SCAN_MID_VALID)) == 0) {
-                excl = wave_reduce_sum((long long)(a & 0xFFFFFFFFull) + (long long)(b & 0xFFFFFFFFull));
+                excl = wave_reduce_sum((long long)(a & ~SCAN_MID_VALID) + (long long)(b & ~SCAN_MID_VALID));
                 ok = true;
             } else {
                 __builtin_amdgcn_s_sleep(1);
             }
         }
-        if (!ok) {   // an earlier block is not running (never observed): sum the input in front of this block
-            long long sacc = 0;
-            for (size_t i = lane; i < (size_t)blk * SCAN_MID_ITEMS; i += 64) sacc += in[i];
-            excl = wave_reduce_sum(sacc);
-        }
+        if (!ok && lane == 0) flags[FLAG_INTERNAL] = 1;
         if (lane == 0) s_excl = excl;
     }
     __syncthreads();
     const long long carry = s_excl;
     int o[8];
-    o[0] = (int)carry + woff + inc - tsum;
+    o[0] = (int)(carry + woff + inc - tsum);
 #pragma unroll
     for (int k = 1; k < 8; ++k) o[k] = o[k - 1] + v[k - 1];
     if (i0 + 8 <= n) {
@@ -359,9 +537,10 @@ __global__ void __launch_bounds__(256) scan_mid_kernel(const int *in, int *out, 
             if (total > 0x7FFFFFFFLL) flags[FLAG_OVERFLOW] = 1;
         }
         // the last block to get here has seen every other block read what it needed: clear the words for the next scan
-        if (atomicAdd(done, 1) == nblk - 1) {
+        if (atomicAdd(&ctl[0], 1) == nblk - 1) {
             for (int b = 0; b < nblk; ++b) __hip_atomic_store(&state[b], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ctl[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -376,18 +555,24 @@ pem_status exclusive_scan_i32(pem_ctx *ctx, const int *in, int *out, size_t n, i
         set_error("exclusive_scan_i32: unaligned pointer");
         return PEM_E_INVALID;
     }
-    if (n <= 8192) {
+    const int force = ctx->dbg_scan_force;   // test hook: 1 one block, 2 chained single launch, 3 three launches
+    if (force == 2 && n > (size_t)SCAN_MID_ITEMS * SCAN_MID_BLOCKS) {
+        set_error("exclusive_scan_i32: the chained scan takes at most %d items", SCAN_MID_ITEMS * SCAN_MID_BLOCKS);
+        return PEM_E_INVALID;
+    }
+    if (force ? force == 1 : n <= 8192) {
         PEM_LAUNCH(ctx, scan_small_kernel, 1, 1024, in, out, n, reinterpret_cast<long long *>(d_total64), ctx->d_flags);
         return PEM_OK;
     }
-    if (n <= (size_t)SCAN_MID_ITEMS * SCAN_MID_BLOCKS) {
+    if (force ? force == 2 : n <= (size_t)SCAN_MID_ITEMS * SCAN_MID_BLOCKS) {
         if (!ctx->scan_state.p) {   // look-back words + completion counter, zero between scans
             PEM_TRY(ctx->scan_state.reserve(sizeof(unsigned long long) * (SCAN_MID_BLOCKS + 2)));
             PEM_HIP(hipMemsetAsync(ctx->scan_state.p, 0, sizeof(unsigned long long) * (SCAN_MID_BLOCKS + 2), ctx->stream));
         }
         unsigned long long *state = ctx->scan_state.as<unsigned long long>();
         PEM_LAUNCH(ctx, scan_mid_kernel, (unsigned)((n + SCAN_MID_ITEMS - 1) / SCAN_MID_ITEMS), 256, in, out, n, state,
-                   reinterpret_cast<int *>(state + SCAN_MID_BLOCKS), reinterpret_cast<long long *>(d_total64), ctx->d_flags);
+                   reinterpret_cast<int *>(state + SCAN_MID_BLOCKS), reinterpret_cast<long long *>(d_total64), ctx->d_flags,
+                   ctx->dbg_scan_stall_ticket);
         return PEM_OK;
     }
     int nblk = (int)((n + SCAN_BLOCK_ITEMS - 1) / SCAN_BLOCK_ITEMS);
@@ -646,6 +831,38 @@ pem_status radix_sort_u64_u32(pem_ctx *ctx, uint64_t *k0, uint64_t *k1, uint32_t
 }
 
 }  // namespace pem
+
+// test hook (include/pem_spgemm.h): the device scan on a caller's array, with the regime forced and one block stalled
+extern "C" pem_status pem_debug_scan_i32(pem_ctx *ctx, const int32_t *in, int64_t n, int regime, int in_place, int stall_ticket, int32_t *out,
+                                         int64_t *total)
+{
+    if (!ctx || n < 0 || (n > 0 && !in) || !out || regime < 0 || regime > 3) return PEM_E_INVALID;
+    PEM_ENTER(ctx);
+    pem::DevBuf dIn, dOut;
+    const size_t sz = sizeof(int) * ((size_t)n + 4);
+    PEM_TRY(dIn.reserve(sz));
+    PEM_TRY(dOut.reserve(sz));
+    PEM_TRY(pem::zero_flags(ctx));
+    if (n) PEM_HIP(hipMemcpyAsync(dIn.p, in, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    ctx->dbg_scan_force = regime;
+    ctx->dbg_scan_stall_ticket = stall_ticket;
+    int *dst = in_place ? dIn.as<int>() : dOut.as<int>();
+    pem_status s = pem::exclusive_scan_i32(ctx, dIn.as<int>(), dst, (size_t)n, ctx->d_scalars + 8);
+    ctx->dbg_scan_force = 0;
+    ctx->dbg_scan_stall_ticket = -1;
+    PEM_TRY(s);
+    int64_t t = 0;
+    PEM_TRY(pem::read_scalars(ctx, ctx->d_scalars + 8, 1, &t));
+    int hf[pem::NUM_FLAGS];
+    PEM_TRY(pem::read_flags(ctx, hf));
+    PEM_HIP(hipMemcpy(out, dst, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost));
+    if (total) *total = t;
+    if (hf[pem::FLAG_INTERNAL]) {
+        pem::set_error("device scan: a block waited for an earlier ticket beyond the poll budget");
+        return PEM_E_HIP;
+    }
+    return PEM_OK;
+}
 
 extern "C" const char *pem_last_error(void) { return pem::last_error(); }
 extern "C" const char *pem_version(void) { return "pem-spgemm_amd 0.1 (gfx950)"; }

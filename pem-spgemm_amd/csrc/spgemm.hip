@@ -14,7 +14,8 @@
 // expand + radix-sort path ("esc") serves oversized rows and PEM_STEP1=esc.  Step 2c is the boolean row
 // product (C row r = OR of B rows kk over kk in A row r), one C tile per lane; step 3 keeps one C entry per
 // lane in a register, accumulates in ascending k with one fma per product, and stores once.  All outputs keep
-// the reference layouts (include/pem_spgemm.h).  Environment switches (A/B baselines kept for tests):
+// the reference layouts (include/pem_spgemm.h).  Kernel variants (A/B baselines kept for tests) are plan options
+// (pem_cplan_set_option); the environment only sets a new plan's defaults:
 //   PEM_STEP1=esc  PEM_WIDE=0  PEM_PRUNE=0  PEM_NO_WARM=1  PEM_EXPORT=rows
 #include "pem_internal.h"
 #include <algorithm>
@@ -845,7 +846,8 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
         }
         // step 2 walks the slots in blocks of 256: note, for every block boundary inside this row's range, the row and
         // the boundary's position in the range (how many of the row's slots lie before it)
-        for (int b = (lp0 + 255) / 256 + tid; b * 256 < lp0 + nlive; b += THREADS) block_info[b] = make_int2(i, b * 256 - lp0);
+        for (long long b = ((long long)lp0 + 255) / 256 + tid; b * 256 < (long long)lp0 + nlive; b += THREADS)   // (64-bit: lp0 + nlive reaches 2^31 - 1)
+            block_info[b] = make_int2(i, (int)(b * 256 - lp0));
         if (tid == 0) row_tc[i] = base;
         S1_DBG_MARK(3);
 #ifdef PEM_S1_DEBUG
@@ -1886,17 +1888,26 @@ extern "C" pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const p
     p->tr_hi = tr_hi;
     p->a_lo = A->h_tile_rowptr[(size_t)tr_lo];
     p->a_hi = A->h_tile_rowptr[(size_t)tr_hi];
-    // Options that change the SIZES of a pass are read once, here: a warm pass re-uses the sizes of the previous one,
-    // so they must not change under a plan.  PEM_S1_FORCE_KEY64 / PEM_S1_XLCAP are test hooks: they push small inputs
-    // through the code a B with more than 2^17 tile columns / a tile row beyond the LDS bins selects.
-    const char *e = getenv("PEM_PRUNE");
-    p->opt_prune = !(e && !strcmp(e, "0"));
-    e = getenv("PEM_S1_FORCE_KEY64");
-    p->opt_key64 = e && !strcmp(e, "1");
-    e = getenv("PEM_S1_XLCAP");
-    p->opt_xlcap = e ? atoi(e) : 0;
-    e = getenv("PEM_S3_BAND");
-    p->opt_band = !(e && !strcmp(e, "0"));
+    // Every switch is a property of the PLAN, latched here (pem_cplan_set_option changes it later): a C ABI whose behaviour
+    // followed the process environment at call time is not a boundary a maintainer can bind.  The environment variables only
+    // give the DEFAULTS a new plan starts from (test hooks: PEM_S1_FORCE_KEY64 / PEM_S1_XLCAP push small inputs through the
+    // code a B with more than 2^17 tile columns / a tile row beyond the LDS bins selects).
+    auto env_is = [](const char *name, const char *val) {
+        const char *e = getenv(name);
+        return e && !strcmp(e, val);
+    };
+    p->opt_prune = !env_is("PEM_PRUNE", "0");
+    p->opt_key64 = env_is("PEM_S1_FORCE_KEY64", "1");
+    {
+        const char *e = getenv("PEM_S1_XLCAP");
+        p->opt_xlcap = e ? atoi(e) : 0;
+    }
+    p->opt_band = !env_is("PEM_S3_BAND", "0");
+    p->opt_step1_esc = env_is("PEM_STEP1", "esc");
+    p->opt_wide = !env_is("PEM_WIDE", "0");
+    p->opt_warm = !env_is("PEM_NO_WARM", "1");
+    p->opt_export_rows = env_is("PEM_EXPORT", "rows");
+    p->opt_s1_serial = getenv("PEM_S1_SERIAL") != nullptr;
     *out = p;
     return PEM_OK;
 }
@@ -1924,6 +1935,64 @@ extern "C" pem_status pem_cplan_get_info(const pem_cplan *p, pem_cplan_info *inf
     info->nnz_c = p->nnz_c;
     info->npairs_all = p->npairs_all;
     return PEM_OK;
+}
+
+static int *plan_option_slot(pem_cplan *p, pem_option which)
+{
+    switch (which) {
+    case PEM_OPT_PRUNE: return &p->opt_prune;
+    case PEM_OPT_STEP1_GLOBAL_SORT: return &p->opt_step1_esc;
+    case PEM_OPT_WIDE: return &p->opt_wide;
+    case PEM_OPT_WARM: return &p->opt_warm;
+    case PEM_OPT_S3_BAND: return &p->opt_band;
+    case PEM_OPT_S1_FORCE_KEY64: return &p->opt_key64;
+    case PEM_OPT_S1_XLCAP: return &p->opt_xlcap;
+    case PEM_OPT_EXPORT_ROWS: return &p->opt_export_rows;
+    case PEM_OPT_S1_SERIAL: return &p->opt_s1_serial;
+    default: return nullptr;
+    }
+}
+
+extern "C" pem_status pem_cplan_set_option(pem_cplan *plan, pem_option which, int64_t value)
+{
+    if (!plan) return PEM_E_INVALID;
+    int *slot = plan_option_slot(plan, which);
+    if (!slot || value < 0 || value > 0x7FFFFFFF) {
+        set_error("pem_cplan_set_option: unknown option %d or value %lld out of range", (int)which, (long long)value);
+        return PEM_E_INVALID;
+    }
+    const int v = which == PEM_OPT_S1_XLCAP ? (int)value : (value != 0);
+    if (*slot == v) return PEM_OK;
+    *slot = v;
+    // a repeat pass re-uses the sizes (and possibly the captured graph) of the previous one: whatever changes the kernels
+    // that run or the sizes they produce starts the plan over
+    plan->warm = false;
+    if (plan->graph_exec) {
+        (void)hipGraphExecDestroy(plan->graph_exec);
+        plan->graph_exec = nullptr;
+    }
+    plan->graph_failed = false;
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_cplan_get_option(const pem_cplan *plan, pem_option which, int64_t *value)
+{
+    if (!plan || !value) return PEM_E_INVALID;
+    const int *slot = plan_option_slot(const_cast<pem_cplan *>(plan), which);
+    if (!slot) {
+        set_error("pem_cplan_get_option: unknown option %d", (int)which);
+        return PEM_E_INVALID;
+    }
+    *value = *slot;
+    return PEM_OK;
+}
+
+// a device-side primitive gave up (the chained scan's bounded wait): fail the call rather than hand back wrong arrays
+static pem_status check_internal(const int *hf)
+{
+    if (!hf[FLAG_INTERNAL]) return PEM_OK;
+    set_error("internal: a device scan ran out of its poll budget; the pass's results are not valid");
+    return PEM_E_HIP;
 }
 
 static pem_status step_elapsed(pem_ctx *ctx, int e0, int e1, double *dst)
@@ -2036,7 +2105,7 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
     (void)hipEventRecord(ctx->ev_fork, main_stream);
     bool forked[3] = {false, false, false};
     int next_aux = -1;                     // -1: the main stream is still free
-    const bool serial = getenv("PEM_S1_SERIAL") != nullptr;   // diagnostic: every bin alone, one after the other
+    const bool serial = p->opt_s1_serial != 0;   // diagnostic: every bin alone, one after the other
     auto bin_begin = [&]() {
         if (next_aux < 0 || serial) return;
         (void)hipStreamWaitEvent(ctx->aux[next_aux], ctx->ev_fork, 0);
@@ -2185,6 +2254,10 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     const size_t n = (size_t)P;
     int64_t TC = 0;
     if (n > 0) {
+        // sizing phase "pairs": everything P-sized comes out of one driver allocation (a repeat pass finds it all in place)
+        PEM_TRY(arena_phase(ctx->arena, {{&p->pairs_a, sizeof(int) * (n + 4)}, {&p->pairs_b, sizeof(int) * (n + 4)},
+                                         {&p->scratch_col, sizeof(int) * (n + 4)}, {&p->scratch_off, sizeof(int) * (n + 4)},
+                                         {&p->block_info, sizeof(int2) * (n / 256 + 4)}}));
         PEM_TRY(p->pairs_a.reserve(sizeof(int) * (n + 4)));
         PEM_TRY(p->pairs_b.reserve(sizeof(int) * (n + 4)));
         PEM_TRY(p->scratch_col.reserve(sizeof(int) * (n + 4)));
@@ -2249,7 +2322,7 @@ static pem_status ensure_compact(pem_ctx *ctx, const pem_cplan *cp)
     if (p->compact_valid || !p->pairs_ready || p->state < 1) return PEM_OK;
     const int mt = p->tr_hi - p->tr_lo;
     const size_t ntc = (size_t)p->ntiles_c;
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
     PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
     if (mt > 0)
@@ -2262,14 +2335,12 @@ static pem_status ensure_compact(pem_ctx *ctx, const pem_cplan *cp)
 
 static pem_status step1_impl(pem_ctx *ctx, pem_cplan *p, bool allow_warm)
 {
-    const char *mode = getenv("PEM_STEP1");
-    const char *nowarm = getenv("PEM_NO_WARM");
     p->warm_pass = false;
-    if (mode && !strcmp(mode, "esc")) {
+    if (p->opt_step1_esc) {
         p->warm = false;
         return step1_esc_impl(ctx, p);
     }
-    p->warm_pass = allow_warm && p->warm && !(nowarm && !strcmp(nowarm, "1"));
+    p->warm_pass = allow_warm && p->warm && p->opt_warm;
     return step1_rows_impl(ctx, p);
 }
 
@@ -2283,15 +2354,19 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
     hipStream_t st = ctx->stream;
     const size_t n = (size_t)p->npairs, ntc = (size_t)p->ntiles_c;
     if (!ctx->chain_events) PEM_HIP(hipEventRecord(ctx->ev[2], st));   // inside pem_spgemm the previous step's end event is the start
+    // sizing phase "C tiles"
+    PEM_TRY(arena_phase(ctx->arena, {{&p->pairs_a, sizeof(int) * (n + 4)}, {&p->pairs_b, sizeof(int) * (n + 4)},
+                                     {&p->c_mask, sizeof(uint32_t) * 8 * (ntc + 1)}, {&p->c_tile_nnz_ptr, sizeof(int) * (ntc + 4)},
+                                     {&p->c_tile_colidx, sizeof(int) * (ntc + 4)}, {&p->pairs_offset, sizeof(int) * (ntc + 4)},
+                                     {&p->group_nnz, sizeof(int) * ((ntc + S2_GROUP - 1) / S2_GROUP + 4)}}));
     PEM_TRY(p->pairs_a.reserve(sizeof(int) * (n + 4)));
     PEM_TRY(p->pairs_b.reserve(sizeof(int) * (n + 4)));
     PEM_TRY(p->c_mask.reserve(sizeof(uint32_t) * 8 * (ntc + 1)));
     PEM_TRY(p->c_tile_nnz_ptr.reserve(sizeof(int) * (ntc + 4)));
     p->c_rowptr_valid = false;
-    const char *wide_env = getenv("PEM_WIDE");
-    // the fused kernel reads the row-local scratch of the default step 1; the global-sort step 1 (PEM_STEP1=esc) and
-    // PEM_WIDE=0 take the 16-lanes-per-tile baseline kernels over the dense layout
-    const bool fused = p->pairs_ready && !(wide_env && !strcmp(wide_env, "0"));
+    // the fused kernel reads the row-local scratch of the default step 1; the global-sort step 1 (PEM_OPT_STEP1_GLOBAL_SORT)
+    // and PEM_OPT_WIDE = 0 take the 16-lanes-per-tile baseline kernels over the dense layout
+    const bool fused = p->pairs_ready && p->opt_wide;
     p->wide = fused;
     p->verify_folded = false;
     int64_t nnzc = 0;
@@ -2302,7 +2377,10 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
             // entry counts of every S2_GROUP tiles, accumulated by s2_tiles_kernel
             const size_t nblk = (n + 255) / 256, ngroups = (ntc + S2_GROUP - 1) / S2_GROUP;
             PEM_TRY(p->group_nnz.reserve(sizeof(int) * (ngroups + 4)));
+            // (step 1's reset clears the counters of a repeat pass; the note holds for ONE step 2 -- a second step 2 on the
+            // same step-1 result, through the step-wise API, must not add onto the scanned counts of the first)
             if (!p->group_nnz_cleared) PEM_HIP(hipMemsetAsync(p->group_nnz.p, 0, sizeof(int) * (ngroups + 4), st));
+            p->group_nnz_cleared = false;
             int *group_nnz = p->group_nnz.as<int>();
             PEM_LAUNCH(ctx, s2_tiles_kernel, (unsigned)nblk, 256, p->scratch_col.as<int>(), p->scratch_off.as<int>(), (long long)n,
                        p->block_info.as<int2>(), p->c_tile_rowptr.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), A->masks.as<uint16_t>(),
@@ -2316,12 +2394,16 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
                 PEM_TRY(read_scalars(ctx, ctx->d_scalars + 2, 1, sc));
                 int hf[NUM_FLAGS];
                 PEM_TRY(read_flags(ctx, hf));
+                PEM_TRY(check_internal(hf));
                 if (hf[FLAG_OVERFLOW] || sc[0] > 0x7FFFFFFFll) {
                     set_error("step 2: C has more than 2^31-1 nonzeros, beyond the int32 range of the reference's offsets");
                     return PEM_E_OVERFLOW;
                 }
                 nnzc = sc[0];
             }
+            // sizing phase "C entries"
+            PEM_TRY(arena_phase(ctx->arena, {{&p->c_rowcolidx, (size_t)nnzc + 16}, {&p->s3_chunk_tile, sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)},
+                                             {&p->c_vals, (size_t)A->value_bytes * ((size_t)nnzc + 1)}}));
             PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
             PEM_TRY(p->s3_chunk_tile.reserve(sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)));
             WarmCheck wc = {};
@@ -2434,7 +2516,7 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
 extern "C" pem_status pem_spgemm_step1(pem_ctx *ctx, pem_cplan *plan)
 {
     if (!ctx || !plan) return PEM_E_INVALID;
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     PEM_TRY(step1_impl(ctx, plan, false));   // step-wise calls always read the sizes back
     PEM_TRY(ensure_compact(ctx, plan));      // ... and leave step 1's outputs in the reference layout
     PEM_HIP(hipStreamSynchronize(ctx->stream));
@@ -2444,7 +2526,8 @@ extern "C" pem_status pem_spgemm_step1(pem_ctx *ctx, pem_cplan *plan)
 extern "C" pem_status pem_spgemm_step2(pem_ctx *ctx, pem_cplan *plan)
 {
     if (!ctx || !plan) return PEM_E_INVALID;
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
+    plan->warm_pass = false;                 // step-wise calls read every size back, also after a warm pem_spgemm on this plan
     PEM_TRY(step2_impl(ctx, plan));
     PEM_HIP(hipStreamSynchronize(ctx->stream));
     return step_elapsed(ctx, 2, 3, &ctx->timings.step2_ms);
@@ -2453,7 +2536,8 @@ extern "C" pem_status pem_spgemm_step2(pem_ctx *ctx, pem_cplan *plan)
 extern "C" pem_status pem_spgemm_step3(pem_ctx *ctx, pem_cplan *plan)
 {
     if (!ctx || !plan) return PEM_E_INVALID;
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
+    plan->warm_pass = false;
     PEM_TRY(step3_impl(ctx, plan));
     PEM_HIP(hipStreamSynchronize(ctx->stream));
     return step_elapsed(ctx, 4, 5, &ctx->timings.step3_ms);
@@ -2471,7 +2555,7 @@ extern "C" pem_status pem_set_graph_replay(pem_ctx *ctx, int on)
 extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
 {
     if (!ctx || !plan) return PEM_E_INVALID;
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     auto t0 = std::chrono::high_resolution_clock::now();
     // back-to-back steps share their boundary events (each record is a barrier packet, ~5 us of pipeline bubble)
     struct Chain {
@@ -2489,9 +2573,7 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
     // the fork onto the auxiliary streams and the joins are captured once and replayed as one hipGraph -- the launch
     // gaps go (3 % of a 2.3 ms pass, 7 % of a 0.27 ms one).  The graph is re-captured whenever any device buffer
     // was (re)allocated since the capture.
-    const char *mode_env = getenv("PEM_STEP1"), *nowarm_env = getenv("PEM_NO_WARM");
-    const bool use_graph = ctx->graph_replay && plan->warm && !ctx->profiling && !(mode_env && !strcmp(mode_env, "esc")) &&
-                           !(nowarm_env && !strcmp(nowarm_env, "1"));
+    const bool use_graph = ctx->graph_replay && plan->warm && !ctx->profiling && !plan->opt_step1_esc && plan->opt_warm;
     bool graphed = false;
     if (use_graph && !plan->graph_failed) {
         if (plan->graph_exec && plan->graph_gen != pem::alloc_generation()) {
@@ -2525,6 +2607,7 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
             PEM_HIP(hipGraphLaunch(plan->graph_exec, ctx->stream));
             int hf[NUM_FLAGS];
             PEM_TRY(read_flags(ctx, hf));
+            PEM_TRY(check_internal(hf));
             if (hf[FLAG_CAPACITY]) {   // sizes differ from the captured ones (cannot happen while A and B are immutable)
                 (void)hipGraphExecDestroy(plan->graph_exec);
                 plan->graph_exec = nullptr;
@@ -2543,6 +2626,7 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
             launch_verify();
             int hf[NUM_FLAGS];
             PEM_TRY(read_flags(ctx, hf));   // the pass's one synchronisation
+            PEM_TRY(check_internal(hf));
             if (hf[FLAG_CAPACITY]) {        // cannot happen while A and B are immutable; recover by a full pass
                 plan->warm = false;
                 PEM_TRY(step1_impl(ctx, plan, false));
@@ -2569,7 +2653,7 @@ static pem_status ensure_c_rowidx(pem_ctx *ctx, const pem_cplan *p)
 {
     if (p->c_rowidx_valid || p->state < 1) return PEM_OK;
     const int mt = p->tr_hi - p->tr_lo;
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     PEM_TRY(p->c_tile_rowidx.reserve(sizeof(int) * ((size_t)p->ntiles_c + 4)));
     if (mt > 0 && p->ntiles_c > 0)
         PEM_LAUNCH(ctx, s1_crowidx_kernel, grid_for((size_t)mt * 64, 256), 256, p->c_tile_rowptr.as<int>(), mt, p->tr_lo, p->c_tile_rowidx.as<int>());
@@ -2582,7 +2666,7 @@ static pem_status ensure_c_rowptr(pem_ctx *ctx, const pem_cplan *p)
 {
     if (p->c_rowptr_valid || p->state < 2) return PEM_OK;
     const size_t ntc = (size_t)p->ntiles_c;
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     PEM_TRY(p->c_rowptr.reserve(16 * (ntc + 1)));
     if (ntc > 0) PEM_LAUNCH(ctx, s2_crowptr_kernel, grid_for(ntc, 256), 256, p->c_mask.as<uint32_t>(), (long long)ntc, p->c_rowptr.as<uint8_t>());
     p->c_rowptr_valid = true;
@@ -2636,7 +2720,7 @@ extern "C" pem_status pem_cplan_get_array(pem_ctx *ctx, const pem_cplan *p, pem_
         return PEM_E_INVALID;
     }
     if (want == 0) return PEM_OK;
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     PEM_HIP(hipMemcpyAsync(host_dst, src, want, hipMemcpyDeviceToHost, ctx->stream));
     PEM_HIP(hipStreamSynchronize(ctx->stream));
     return PEM_OK;
@@ -2661,15 +2745,14 @@ static pem_status export_csr_device_impl(pem_ctx *ctx, const pem_cplan *p, int32
     }
     if (!export_type_ok(p, (int)sizeof(VT), "pem_c_export_csr")) return PEM_E_INVALID;
     if (p->nnz_c > 0 && (!d_colidx || !d_vals)) return PEM_E_INVALID;
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     hipStream_t st = ctx->stream;
     const int mt = p->tr_hi - p->tr_lo;
     const int r0 = p->tr_lo * 16, r1 = p->tr_hi * 16 < p->A->rows ? p->tr_hi * 16 : p->A->rows;
     const int nrows = r1 - r0;
     PEM_HIP(hipEventRecord(ctx->ev[6], st));
     PEM_HIP(hipMemsetAsync(d_rowptr, 0, sizeof(int) * ((size_t)nrows + 1), st));
-    const char *narrow = getenv("PEM_EXPORT");
-    if (mt > 0 && nrows > 0 && narrow && !strcmp(narrow, "rows")) {   // 16 lanes per tile row, serial over its tiles (A/B baseline)
+    if (mt > 0 && nrows > 0 && p->opt_export_rows) {   // 16 lanes per tile row, serial over its tiles (A/B baseline)
         PEM_TRY(ensure_c_rowptr(ctx, p));
         PEM_LAUNCH(ctx, ex_rowcount_kernel, grid_for((size_t)mt * 16, 256), 256, p->c_tile_rowptr.as<int>(), p->c_mask.as<uint16_t>(), mt, nrows,
                    d_rowptr);
@@ -2710,7 +2793,7 @@ static pem_status export_csr_impl(pem_ctx *ctx, const pem_cplan *p, int64_t *nnz
     if (nnz) *nnz = p->nnz_c;
     if (!rowptr) return PEM_OK;   // size query
     if (!export_type_ok(p, (int)sizeof(VT), "pem_c_export_csr")) return PEM_E_INVALID;
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     const int r0 = p->tr_lo * 16, r1 = p->tr_hi * 16 < p->A->rows ? p->tr_hi * 16 : p->A->rows;
     const size_t nrows = (size_t)(r1 - r0), nz = (size_t)p->nnz_c;
     DevBuf dR, dC, dV;
@@ -2780,7 +2863,7 @@ extern "C" pem_status pem_split_tile_rows(pem_ctx *ctx, const pem_tiled *A, cons
         set_error("pem_split_tile_rows: inner dimensions differ");
         return PEM_E_INVALID;
     }
-    PEM_HIP(hipSetDevice(ctx->device));
+    PEM_ENTER(ctx);
     const int mt = A->tile_rows;
     DevBuf &rp = ctx->tmp[3];
     PEM_TRY(rp.reserve(sizeof(long long) * ((size_t)mt + 1)));

@@ -118,7 +118,7 @@ def test_narrow_step23_kernels_match(pkg, oracle, ctx, name, monkeypatch):
 
 def test_repeat_passes_skip_readbacks_and_stay_identical(pkg, oracle, ctx, monkeypatch):
     """pem_spgemm on an unchanged plan re-uses the sizes of the previous pass (no host read-backs, device-side
-    check); results must stay identical, also against a forced cold pass (PEM_NO_WARM=1)."""
+    check); results must stay identical, also against a forced size-reading pass (PEM_OPT_WARM = 0)."""
     from matgen import cases as _cases
     for name in ("powerlaw_600", "hub_row_4000", "empty_matrix", "blockrows_10000"):
         gA, gB, oA, oB = _tiled_pair(pkg, oracle, ctx, CASES[name])
@@ -128,10 +128,10 @@ def test_repeat_passes_skip_readbacks_and_stay_identical(pkg, oracle, ctx, monke
         for _ in range(3):
             plan.spgemm()                  # warm
         warm = [plan.array(a) for a in C_NAMES]
-        monkeypatch.setenv("PEM_NO_WARM", "1")
+        plan.set_option("warm", 0)         # every pass reads its sizes back (the environment is only read at plan creation)
         plan.spgemm()
         forced = [plan.array(a) for a in C_NAMES]
-        monkeypatch.delenv("PEM_NO_WARM")
+        plan.set_option("warm", 1)
         want_arrays, _ = expected(oracle.Plan(oA, oB), oA, oB)
         for a, c, w, f in zip(C_NAMES, cold, warm, forced):
             want = want_arrays[a]
@@ -140,12 +140,14 @@ def test_repeat_passes_skip_readbacks_and_stay_identical(pkg, oracle, ctx, monke
 
 @pytest.mark.parametrize("name", ["powerlaw_600", "hub_row_4000", "ragged_37", "empty_rows"])
 def test_row_serial_export_matches(pkg, oracle, ctx, name, monkeypatch):
-    """PEM_EXPORT=rows selects the 16-lanes-per-tile-row export (A/B baseline of the chunked export)."""
+    """PEM_OPT_EXPORT_ROWS selects the 16-lanes-per-tile-row export (A/B baseline of the chunked export)."""
     gA, gB, oA, oB = _tiled_pair(pkg, oracle, ctx, CASES[name])
     plan = pkg.CPlan(ctx, gA, gB)
     plan.spgemm()
     fast = plan.export_csr()
-    monkeypatch.setenv("PEM_EXPORT", "rows")
+    plan.set_option("export_rows", 1)
+    assert plan.get_option("export_rows") == 1
+    plan.spgemm()                         # (changing an option restarts the plan: the next pass is a full one)
     slow = plan.export_csr()
     want = oracle.Plan(oA, oB).export_csr()
     for a, b, c in zip(fast, slow, want):

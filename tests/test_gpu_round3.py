@@ -1,0 +1,149 @@
+"""GPU: round-3 host-side fixes -- step-wise calls after warm passes, the ticketed device scan, the context arena, plan options."""
+import numpy as np
+import pytest
+
+from matgen import cases
+from prune_ref import expected
+
+pytestmark = pytest.mark.gpu
+
+CASES = cases()
+C_NAMES = ["c_tile_rowptr", "c_tile_rowidx", "c_tile_colidx", "pairs_offset", "pairs_a", "pairs_b", "c_mask", "c_tile_nnz_ptr",
+           "c_rowptr", "c_rowcolidx", "c_vals"]
+
+
+def _pair(pkg, oracle, ctx, case):
+    rows, cols, I, J, V, tr = case
+    gA = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V, False)
+    gB = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V, True) if tr else gA
+    oA = oracle.Tiled(rows, cols, I, J, V, False)
+    oB = oracle.Tiled(rows, cols, I, J, V, True) if tr else oA
+    return gA, gB, oA, oB
+
+
+@pytest.mark.parametrize("name", ["powerlaw_600", "hub_row_4000", "band_1500"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_stepwise_calls_after_warm_passes(pkg, oracle, ctx, name, graph):
+    """pem_spgemm_step2 / step3 may follow a warm (or graph-replayed) pem_spgemm on the same plan: step 2 then runs again on
+    step 1's result of that pass and must not add onto the group counters the pass has already scanned (round-2 advisor
+    finding: c_tile_nnz_ptr / c_rowcolidx came out wrong and step 3 produced garbage, status PEM_OK)."""
+    gA, gB, oA, oB = _pair(pkg, oracle, ctx, CASES[name])
+    plan = pkg.CPlan(ctx, gA, gB)
+    ctx.set_graph_replay(graph)
+    try:
+        for _ in range(3):
+            plan.spgemm()
+        plan.step2()
+        plan.step3()
+        plan.step2()          # and once more: every step 2 clears what it accumulates into
+        plan.step3()
+    finally:
+        ctx.set_graph_replay(False)
+    want_arrays, want_counts = expected(oracle.Plan(oA, oB), oA, oB)
+    info = plan.info()
+    assert (info["ntiles_c"], info["npairs"], info["nnz_c"], info["npairs_all"]) == want_counts
+    for arr in C_NAMES:
+        assert np.array_equal(plan.array(arr), want_arrays[arr]), f"{name}: {arr} differs after step-wise calls on a warm plan"
+    plan.spgemm()             # ... and the plan is still good for whole passes
+    for arr in C_NAMES:
+        assert np.array_equal(plan.array(arr), want_arrays[arr]), f"{name}: {arr} differs on the pass after"
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 2048, 2049, 8192, 8193, 70001, 262144])
+def test_device_scan_regimes_agree(pkg, ctx, n):
+    """the one-block, the chained single-launch and the three-launch scan give numpy's prefix sums, in place and out of place"""
+    rng = np.random.default_rng(n + 1)
+    v = rng.integers(0, 1000, n).astype(np.int32)
+    want = np.concatenate([[0], np.cumsum(v, dtype=np.int64)]).astype(np.int32)
+    for regime in (0, 1, 2, 3):
+        for in_place in (True, False):
+            got, total = ctx.debug_scan(v, regime=regime, in_place=in_place)
+            assert total == int(v.sum()), (regime, in_place)
+            assert np.array_equal(got, want), f"regime {regime} in_place {in_place}: scan of {n} items differs"
+
+
+@pytest.mark.parametrize("stall", [0, 1, 17, 33])
+def test_chained_scan_survives_a_stalled_block_in_place(pkg, ctx, stall):
+    """Round-2 finding: the chained scan's fallback re-summed an input that in-place callers had already overwritten.  There
+    is no fallback any more -- blocks draw tickets and wait only for tickets that are running.  One block is made to stall
+    ~0.2 ms before it publishes (thousands of polls for everyone behind it); the in-place result must equal the one-block
+    scan's."""
+    n = 34 * 2048 + 77
+    rng = np.random.default_rng(stall)
+    v = rng.integers(0, 30000, n).astype(np.int32)
+    ref, tref = ctx.debug_scan(v, regime=1, in_place=False)
+    got, total = ctx.debug_scan(v, regime=2, in_place=True, stall_ticket=stall)
+    assert total == tref == int(v.astype(np.int64).sum())
+    assert np.array_equal(got, ref)
+    again, _ = ctx.debug_scan(v, regime=2, in_place=True)          # the tickets were handed back: the next scan starts at 0
+    assert np.array_equal(again, ref)
+
+
+def test_scan_overflow_is_flagged_not_wrapped(pkg, ctx):
+    """a total beyond int32 must reach the caller as 64 bits (the hot path turns it into PEM_E_OVERFLOW)"""
+    v = np.full(3000, 2_000_000, dtype=np.int32)                    # 6e9
+    for regime in (1, 2, 3):
+        _, total = ctx.debug_scan(v, regime=regime, in_place=True)
+        assert total == 6_000_000_000, regime
+
+
+def test_arena_serves_a_second_plan_without_the_driver(pkg, oracle, ctx):
+    """The context's arena keeps what a destroyed plan gives back: a fresh plan of the same product makes no driver
+    allocation at all, and a first plan makes at most one per sizing phase (pairs / C tiles / C entries) beyond what the
+    arena already holds."""
+    rows, cols, I, J, V, tr = CASES["powerlaw_600"]
+    gA = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V)
+    before = ctx.memory_stats()
+    plan = pkg.CPlan(ctx, gA, gA)
+    plan.spgemm()
+    first = plan.export_csr()
+    mid = ctx.memory_stats()
+    assert mid["driver_allocs"] - before["driver_allocs"] <= 4
+    assert mid["in_use_bytes"] > before["in_use_bytes"]
+    plan.close()
+    after_close = ctx.memory_stats()
+    assert after_close["in_use_bytes"] == before["in_use_bytes"], "a destroyed plan must return every block to the arena"
+    plan2 = pkg.CPlan(ctx, gA, gA)
+    plan2.spgemm()
+    second = plan2.export_csr()
+    end = ctx.memory_stats()
+    assert end["driver_allocs"] == mid["driver_allocs"], "the second plan must be served from the arena"
+    for a, b in zip(first, second):
+        assert np.array_equal(a, b)
+    plan2.close()
+    ctx.reserve(8 << 20)                       # a free block that large exists by now: no driver call
+    assert ctx.memory_stats()["driver_allocs"] == end["driver_allocs"]
+    ctx.trim()
+    assert ctx.memory_stats()["slab_bytes"] <= end["slab_bytes"]
+    plan3 = pkg.CPlan(ctx, gA, gA)             # trimming must leave the context usable
+    plan3.spgemm()
+    for a, b in zip(first, plan3.export_csr()):
+        assert np.array_equal(a, b)
+
+
+def test_plan_options_through_the_abi(pkg, oracle, ctx):
+    """kernel variants are plan options (pem_cplan_set_option), not environment reads at call time: flipping them on a live
+    plan restarts it and every variant still gives the oracle's arrays"""
+    gA, gB, oA, oB = _pair(pkg, oracle, ctx, CASES["hub_row_4000"])
+    op = oracle.Plan(oA, oB)
+    pruned, pruned_counts = expected(op, oA, oB)
+    unpruned, unpruned_counts = expected(op, oA, oB, False)
+    plan = pkg.CPlan(ctx, gA, gB)
+    assert plan.get_option("prune") == 1 and plan.get_option("wide") == 1 and plan.get_option("warm") == 1
+    plan.spgemm()
+    plan.spgemm()
+    for opts, want, counts in (({"wide": 0}, pruned, pruned_counts), ({"wide": 1, "step1_global_sort": 1}, pruned, pruned_counts),
+                               ({"step1_global_sort": 0, "prune": 0}, unpruned, unpruned_counts),
+                               ({"prune": 1, "s1_xlcap": 40}, pruned, pruned_counts), ({"s1_xlcap": 0, "s1_force_key64": 1}, pruned, pruned_counts),
+                               ({"s1_force_key64": 0, "warm": 0}, pruned, pruned_counts)):
+        for k, v in opts.items():
+            plan.set_option(k, v)
+            assert plan.get_option(k) == v
+        for _ in range(2):
+            plan.spgemm()
+            info = plan.info()
+            assert (info["ntiles_c"], info["npairs"], info["nnz_c"], info["npairs_all"]) == counts, opts
+            for arr in C_NAMES:
+                assert np.array_equal(plan.array(arr), want[arr]), f"{opts}: {arr} differs"
+    with pytest.raises(pkg.PemError):
+        pkg._check(pkg.lib().pem_cplan_set_option(plan._h, 99, pkg.C.c_int64(1)))
