@@ -168,7 +168,9 @@ typedef enum {
     PEM_OPT_S1_FORCE_KEY64 = 5,     /* test hook: 64-bit sort keys whatever B's width                                          */
     PEM_OPT_S1_XLCAP = 6,           /* test hook: tile rows with more live products take the global path (0: off)              */
     PEM_OPT_EXPORT_ROWS = 7,        /* 0 (default): balanced chunk export; 1: 16 lanes per tile row (A/B baseline)             */
-    PEM_OPT_S1_SERIAL = 8           /* diagnostic: step 1's row bins one after the other instead of concurrently               */
+    PEM_OPT_S1_SERIAL = 8,          /* diagnostic: step 1's row bins one after the other instead of concurrently               */
+    PEM_OPT_S3_DECODE = 9           /* 1 (default): on plans with < 2 pairs per C tile step 3 reads (row, column) off the C masks and
+                                       Ctiles_rowColIdx is materialised on demand; 0: step 2 writes it on every pass               */
 } pem_option;
 pem_status pem_cplan_set_option(pem_cplan *plan, pem_option which, int64_t value);
 pem_status pem_cplan_get_option(const pem_cplan *plan, pem_option which, int64_t *value);
@@ -207,7 +209,7 @@ typedef enum {
     PEM_C_MASK,              /* uint32[8 T_C] (row 2q)<<16 | row 2q+1           spgemm.cu:533-543 */
     PEM_C_TILE_NNZ_PTR,      /* int32[T_C+1]                                    spgemm.cu:546, 1288 */
     PEM_C_ROWPTR,            /* uint8[16 T_C]                                   spgemm.cu:579-580 */
-    PEM_C_ROWCOLIDX,         /* uint8[C_nnz]                                    spgemm.cu:582-587 */
+    PEM_C_ROWCOLIDX,         /* uint8[C_nnz] (on demand where step 3 decodes)   spgemm.cu:582-587 */
     PEM_C_VALS               /* double[C_nnz] (float for an fp32 plan)          spgemm.cu:643-656 */
 } pem_cplan_array;
 pem_status pem_cplan_get_array(pem_ctx *ctx, const pem_cplan *plan, pem_cplan_array which, void *host_dst, int64_t bytes);

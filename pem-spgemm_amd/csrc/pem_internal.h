@@ -289,12 +289,17 @@ struct pem_cplan {
     int opt_prune = 1, opt_key64 = 0, opt_xlcap = 0;
     int opt_band = 1;                                  // 0: many-pair tiles stay in the entry-per-lane kernel
     int opt_step1_esc = 0, opt_wide = 1, opt_warm = 1, opt_export_rows = 0, opt_s1_serial = 0;
+    int opt_decode = 1;                                // shallow plans: step 3 reads (row, column) off the C masks, no Ctiles_rowColIdx on the pass
     int64_t ntiles_c = 0, npairs = 0, nnz_c = 0;
     pem::DevBuf c_tile_rowptr, c_tile_colidx;
     mutable pem::DevBuf c_tile_rowidx; // _C_tileRowIdx: on demand from c_tile_rowptr on the row-local path (no reader there)
     mutable bool c_rowidx_valid = false;
     pem::DevBuf pairs_offset, pairs_a, pairs_b;
-    pem::DevBuf c_mask, c_tile_nnz_ptr, c_rowcolidx, c_vals;
+    pem::DevBuf c_mask, c_tile_nnz_ptr, c_vals;
+    mutable pem::DevBuf c_rowcolidx;   // Ctiles_rowColIdx: written by step 2 on deep plans, else on demand from c_mask (ensure_c_rowcolidx)
+    mutable bool c_rowcolidx_valid = false;
+    pem::DevBuf c_tile_cnt;            // uint16 per C tile: its entry count (s2_tiles_kernel -> s2_offsets_kernel), decode plans only
+    bool s3_decode = false;            // this pass: step 3 reads (row, column) off the masks
     pem::DevBuf s3_chunk_tile;         // first C tile of every S3_CHUNK-entry chunk of C (written by step 2d for step 3's waves)
     mutable pem::DevBuf c_rowptr;      // Ctiles_rowPtr: materialised on demand from c_mask (nothing on the default path reads it)
     mutable bool c_rowptr_valid = false;

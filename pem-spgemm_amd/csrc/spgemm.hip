@@ -1164,7 +1164,7 @@ __global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ s
                                                        const int *__restrict__ pairs_a, const int *__restrict__ pairs_b,
                                                        const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks, long long ntc,
                                                        int *__restrict__ c_colidx, int *__restrict__ pairs_offset, uint32_t *__restrict__ c_mask,
-                                                       int *__restrict__ group_nnz)
+                                                       int *__restrict__ group_nnz, uint16_t *__restrict__ c_cnt)
 {
     __shared__ unsigned bl[8][256];
     __shared__ int w_tiles[4];
@@ -1242,6 +1242,7 @@ __global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ s
     if (!store) return;
     c_colidx[t] = col;
     pairs_offset[t] = p0;
+    if (c_cnt) c_cnt[t] = (uint16_t)nnz_t;      // the entry offsets then come from 2 bytes per tile, not from its 32-byte mask
     // reference packing: word q = (row 2q) << 16 | row 2q+1  (spgemm.cu:533-543)
     *reinterpret_cast<uint4 *>(c_mask + 8 * t) = make_uint4((cw[0] << 16) | (cw[0] >> 16), (cw[1] << 16) | (cw[1] >> 16),
                                                             (cw[2] << 16) | (cw[2] >> 16), (cw[3] << 16) | (cw[3] >> 16));
@@ -1315,6 +1316,62 @@ __global__ void __launch_bounds__(S2_GROUP) s2_entries_kernel(const uint32_t *__
     s2_emit_rowcol(cw, c_rowcolidx + off);
 }
 
+// The same offsets without the entries: where step 3 reads an entry's (row, column) off the tile's mask (DECODE below),
+// nothing on the pass needs the (r<<4|c) bytes, and the offsets come from the 2-byte entry counts s2_tiles_kernel left --
+// 39 MB in, 78 MB out on webbase-1M, where s2_entries_kernel re-reads 618 MB of masks to emit 69 MB of bytes (0.18 ms
+// against 0.03).  The bytes (Ctiles_rowColIdx, spgemm.cu:582-587) are then materialised on demand like Ctiles_rowPtr
+// (ensure_c_rowcolidx).
+__global__ void __launch_bounds__(256) s2_offsets_kernel(const uint16_t *__restrict__ c_cnt, long long ntc, const int *__restrict__ group_base,
+                                                         int *__restrict__ c_tile_nnz_ptr, int *__restrict__ chunk_tile, int *__restrict__ flags,
+                                                         WarmCheck wc, const long long *__restrict__ d_scalars, const int *__restrict__ bin_count)
+{
+    // one WAVE per group of S2_GROUP = 256 tiles, four consecutive tiles per lane (one 8-byte load, one 16-byte store): the
+    // group's base comes from the scanned group counts, so no wave waits for another (one tile per lane and a block scan
+    // took 73 us)
+    static_assert(S2_GROUP == 256, "four tiles per lane of one wave");
+    const int lane = threadIdx.x & 63;
+    const long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wc.on && g == 0 && lane == 0) warm_check(wc, d_scalars, bin_count, flags);
+    const long long t = g * S2_GROUP + 4 * lane;
+    if (t > ntc) return;                                    // (only lanes above a live one leave: the scan below reads downwards)
+    int n[4] = {0, 0, 0, 0};
+    if (t + 4 <= ntc) {
+        const uint2 q = *reinterpret_cast<const uint2 *>(c_cnt + t);
+        n[0] = (int)(q.x & 0xFFFFu);
+        n[1] = (int)(q.x >> 16);
+        n[2] = (int)(q.y & 0xFFFFu);
+        n[3] = (int)(q.y >> 16);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) n[k] = t + k < ntc ? (int)c_cnt[t + k] : 0;
+    }
+    const int tsum = n[0] + n[1] + n[2] + n[3];
+    int inc = tsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    int o4[4];
+    o4[0] = group_base[g] + inc - tsum;
+    o4[1] = o4[0] + n[0];
+    o4[2] = o4[1] + n[1];
+    o4[3] = o4[2] + n[2];
+    if (t + 4 <= ntc) {
+        *reinterpret_cast<int4 *>(c_tile_nnz_ptr + t) = make_int4(o4[0], o4[1], o4[2], o4[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (t + k <= ntc) c_tile_nnz_ptr[t + k] = o4[k];             // (t + k == ntc: the closing offset = C_nnz)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (t + k >= ntc) break;
+        const long long off = o4[k];
+        for (long long ch = (off + S3_CHUNK - 1) / S3_CHUNK; ch * S3_CHUNK < off + n[k]; ++ch) chunk_tile[ch] = (int)(t + k);
+    }
+}
+
 // Ctiles_rowPtr (spgemm.cu:579-580) from the stored masks, one C tile per lane.  Nothing on the default path reads
 // it (step 3 and the export work from the masks), so it is materialised on demand: 16 bytes per C tile that the
 // mask kernel no longer writes on every pass (0.3 GB on webbase-1M).
@@ -1348,14 +1405,23 @@ constexpr int S3_BAND_MIN = 8;       // C tiles with at least this many pairs go
 constexpr int S3_BAND_CH = 16;       // pairs whose records one wave stages in LDS at a time (multiple of 4, at most 64)
 constexpr int S3_BAND_RS = S3_BAND_CH + 4;   // row stride of the staged records (words): 16-byte aligned, rows on different banks
 constexpr int S3_BAND_H = 1;         // meeting pairs a lane sums per trip of the gather loop
-template <typename VT, bool DEEP, bool BAND = false>
+// DECODE: the entries' (row, column) are read off the C tile's mask instead of Ctiles_rowColIdx.  The 64 tiles a wave holds
+// one per lane put their mask words and their intra-tile row pointers (the sixteen bytes of Ctiles_rowPtr, spgemm.cu:579-580)
+// into a wave-private patch of LDS; entry n of a tile then finds its row by a 4-step search over those bytes (they never
+// decrease) and its column as the k-th set bit of the row's mask: ~35 VALU and two LDS reads per entry in place of a global
+// byte load, and step 2 no longer has to write (or re-read its masks for) the bytes at all.
+template <typename VT, bool DEEP, bool BAND = false, bool DECODE = false>
 __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b, long long ntc,
     const int *__restrict__ c_tile_nnz_ptr, long long nnz_c, const uint8_t *__restrict__ c_rowcolidx, VT *__restrict__ c_vals,
     const int *__restrict__ a_nnz_ptr, const VT *__restrict__ a_vals, const uint32_t *__restrict__ a_rec,
     const int *__restrict__ b_nnz_ptr, const VT *__restrict__ b_vals_t, const uint32_t *__restrict__ b_rec_t,
-    const int *__restrict__ chunk_tile)
+    const int *__restrict__ chunk_tile, const uint32_t *__restrict__ c_mask)
 {
+    __shared__ __attribute__((aligned(16))) uint4 s_rp[DECODE ? 4 * 64 : 1];        // [wave][tile]: prefix counts of the tile's 16 rows, one byte each
+    __shared__ unsigned s_mw[DECODE ? 4 * 8 * 64 : 1];                                // [wave][word q][tile]: (row 2q) << 16 | row 2q+1
+    uint4 *const my_rp = s_rp + (DECODE ? (threadIdx.x >> 6) * 64 : 0);
+    unsigned *const my_mw = s_mw + (DECODE ? (threadIdx.x >> 6) * 8 * 64 : 0);
     // Work is dealt by ENTRIES, S3_EPW per wave, so hub rows (tiles with many entries and pairs) cannot pile
     // up in one wave.  The wave starts at the tile its first entry lies in (noted by step 2d; a 64-ary search over
     // the tile offsets -- three dependent gathers per wave -- before that), then walks the tiles 64 at a time:
@@ -1384,6 +1450,28 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
         const int chunk_end = c_tile_nnz_ptr[tend];
         const int first = __shfl(my_off, 0, 64);
         if (first >= e_hi) break;
+        if constexpr (DECODE) {
+            const uint4 M0 = *reinterpret_cast<const uint4 *>(c_mask + 8 * tl), M1 = *reinterpret_cast<const uint4 *>(c_mask + 8 * tl + 4);
+            const unsigned w[8] = {M0.x, M0.y, M0.z, M0.w, M1.x, M1.y, M1.z, M1.w};   // word q = (row 2q) << 16 | row 2q+1
+            unsigned rp[4] = {0, 0, 0, 0};
+            int run = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                rp[q >> 1] |= (unsigned)run << (16 * (q & 1));
+                run += __popc(w[q] >> 16);
+                rp[q >> 1] |= (unsigned)run << (16 * (q & 1) + 8);
+                run += __popc(w[q] & 0xFFFFu);
+            }
+            // (a full tile's last prefix is 240: everything fits a byte)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the previous 64 tiles' entries have been read
+            __builtin_amdgcn_wave_barrier();
+            my_rp[lane] = make_uint4(rp[0], rp[1], rp[2], rp[3]);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) my_mw[q * 64 + lane] = w[q];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
         const int e_begin = first > e_lo ? first : e_lo, e_end = chunk_end < e_hi ? chunk_end : e_hi;
     for (int ebase = e_begin; ebase < e_end; ebase += 64) {   // wave-uniform trip count: every lane stays live for the shuffles
         const int e = ebase + lane;
@@ -1399,10 +1487,44 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
         const int a0 = __shfl(my_a0, ti, 64), b0 = __shfl(my_b0, ti, 64), av0 = __shfl(my_av0, ti, 64), bv0 = __shfl(my_bv0, ti, 64);
         // (every shuffle sits in front of the `continue`: a lane that has left cannot be read from)
         const int a1 = __shfl(my_a1, ti, 64), b1 = __shfl(my_b1, ti, 64), av1 = __shfl(my_av1, ti, 64), bv1 = __shfl(my_bv1, ti, 64);
+        const int toff = DECODE ? __shfl(my_off, ti, 64) : 0;
         if (!valid) continue;
         if (BAND && p1 - p0 >= S3_BAND_MIN) continue;   // many-pair tiles: s3_band_kernel's
-        const unsigned rc = c_rowcolidx[e];
-        const int r = rc >> 4, c = rc & 15;
+        int r, c;
+        if constexpr (DECODE) {
+            const unsigned n = (unsigned)(e - toff);                     // entry n of its tile, row-major
+            const uint4 rp = my_rp[ti];
+            // largest row r with prefix[r] <= n (the prefixes never decrease, so rows without entries are stepped over)
+            const bool h8 = (rp.z & 0xFFu) <= n;
+            const unsigned d0 = h8 ? rp.z : rp.x, d1 = h8 ? rp.w : rp.y;
+            const bool h4 = (d1 & 0xFFu) <= n;
+            const unsigned d = h4 ? d1 : d0;
+            const bool h2 = ((d >> 16) & 0xFFu) <= n;
+            const unsigned hh = h2 ? d >> 16 : d & 0xFFFFu;
+            const bool h1 = (hh >> 8) <= n;
+            r = (h8 ? 8 : 0) + (h4 ? 4 : 0) + (h2 ? 2 : 0) + (h1 ? 1 : 0);
+            unsigned k = n - (h1 ? hh >> 8 : hh & 0xFFu);               // ... and the k-th entry of that row
+            const unsigned word = my_mw[(r >> 1) * 64 + ti];
+            unsigned m = (r & 1) ? word & 0xFFFFu : word >> 16;
+            unsigned t8 = __popc(m & 0xFFu);
+            const bool g8 = k >= t8;
+            k -= g8 ? t8 : 0u;
+            m = g8 ? m >> 8 : m;
+            unsigned t4 = __popc(m & 0xFu);
+            const bool g4 = k >= t4;
+            k -= g4 ? t4 : 0u;
+            m = g4 ? m >> 4 : m;
+            unsigned t2 = __popc(m & 3u);
+            const bool g2 = k >= t2;
+            k -= g2 ? t2 : 0u;
+            m = g2 ? m >> 2 : m;
+            const bool g1 = k >= (m & 1u);
+            c = (g8 ? 8 : 0) + (g4 ? 4 : 0) + (g2 ? 2 : 0) + (g1 ? 1 : 0);
+        } else {
+            const unsigned rc = c_rowcolidx[e];
+            r = rc >> 4;
+            c = rc & 15;
+        }
         VT acc = VT(0);
         int p = p0;
         if (!DEEP) {   // first pair: everything but the two records and the values is already here
@@ -1704,14 +1826,22 @@ __global__ void __launch_bounds__(256) ex_fill_kernel(const int *__restrict__ c_
 
 // ------------------------------------------------------------------------------------------
 // a14 export, balanced form (default).  CSR order inside a tile row is (row r, tile col, c), the tiled
-// order is (tile col, r, c): a stable 16-bucket partition per tile row.  Tile rows are cut into chunks
-// of 64 consecutive tiles, one wave per chunk, one tile per lane:
-//   ex_chunkhist  per chunk, the entry count of each of the 16 rows        (reads the 32-byte C masks)
-//   ex_chunkscan  per tile row, exclusive scan of its chunks' counts -> chunk bases, row totals
-//   (device scan of the row totals -> CSR row pointer)
-//   ex_chunkfill  per chunk: lane-exclusive prefix of the row counts by shuffles, then every lane
-//                 streams its tile's entries to rowptr[row] + chunk base + prefix
-// Neighbouring lanes hold neighbouring tiles of the same tile row, so their writes to a row abut.
+// order is (tile col, r, c): a stable 16-bucket partition per tile row.  And a tile row's CSR segment starts
+// where its first tile's entries start (tiles are sorted by tile row), so the CSR row pointer needs no scan
+// over the rows: rowptr[16 i + r] = Ctiles_nnz_ptr[first tile of row i] + (entries of rows < r in tile row i).
+// Tile rows are cut into chunks of 64 consecutive tiles, one wave per chunk, one tile per lane:
+//   ex_chunkcount + scan   chunks per tile row -> first chunk of every tile row
+//   ex_chunkrow    the tile row of every chunk (one table instead of a search in every wave of the two kernels below)
+//   ex_chunkhist   per chunk, the entry count of each of the 16 rows        (reads the 32-byte C masks)
+//   ex_chunkscan   one wave per tile row: exclusive scan of its chunks' counts (four chunks x sixteen rows per trip)
+//                  -> chunk bases; the rows' totals -> the CSR row pointer
+//   ex_chunkfill   one C ENTRY per lane: the wave's 64 tiles put their row prefixes, mask words and per-row exclusive
+//                  tile prefixes into LDS; an entry finds its tile by a shuffle search over the tiles' offsets, its
+//                  (row, rank in the row, column) off the mask (as step 3's DECODE does), and goes to
+//                  rowptr[row] + chunk base + tiles before + rank.  Values are read in tiled order -- coalesced --
+//                  and land inside the tile row's own CSR segment (a few tens of KB: the L2 merges the lines).
+// The first form of ex_chunkfill gave every lane one TILE and walked its entries serially: ~100 vector-memory
+// instructions per 64 tiles against ~16 here; it took 1.17 of the export's 1.52 ms on webbase-1M (now 0.51 of 0.83).
 // ------------------------------------------------------------------------------------------
 __global__ void ex_chunkcount_kernel(const int *__restrict__ c_tile_rowptr, int mt, int *__restrict__ chunkcnt)
 {
@@ -1719,21 +1849,12 @@ __global__ void ex_chunkcount_kernel(const int *__restrict__ c_tile_rowptr, int 
     if (i < mt) chunkcnt[i] = (c_tile_rowptr[i + 1] - c_tile_rowptr[i] + 63) >> 6;
 }
 
-// tile row of chunk ch: largest i in [0, mt) with chunkptr[i] <= ch, by a 64-ary search (one gather + ballot per level)
-__device__ __forceinline__ int ex_chunk_row(const int *__restrict__ chunkptr, int mt, int ch, int lane)
+__global__ void __launch_bounds__(256) ex_chunkrow_kernel(const int *__restrict__ chunkptr, int mt, int *__restrict__ chunk_row)
 {
-    int lo = 0, hi = mt;
-    while (hi - lo > 64) {
-        const int step = (hi - lo + 63) >> 6;
-        const int idx = lo + lane * step;
-        const bool le = idx < hi && chunkptr[idx] <= ch;
-        const int k = __popcll(__ballot(le));
-        const int nlo = lo + (k - 1) * step;
-        hi = nlo + step < hi ? nlo + step : hi;
-        lo = nlo;
-    }
-    const bool le = lo + lane < hi && chunkptr[lo + lane] <= ch;
-    return lo + __popcll(__ballot(le)) - 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave; i < mt; i += nwaves)
+        for (int ch = chunkptr[i] + lane; ch < chunkptr[i + 1]; ch += 64) chunk_row[ch] = i;
 }
 
 // per-row entry counts of one C tile packed as 16-bit fields: p[j] holds rows 4j..4j+3 (a chunk sums to <= 1024 per row)
@@ -1746,13 +1867,14 @@ __device__ __forceinline__ void ex_pack_counts(const uint4 M0, const uint4 M1, u
                ((unsigned long long)__popc(w[2 * j + 1] >> 16) << 32) | ((unsigned long long)__popc(w[2 * j + 1] & 0xFFFFu) << 48);
 }
 
-__global__ void __launch_bounds__(256) ex_chunkhist_kernel(const int *__restrict__ chunkptr, int mt, const int *__restrict__ c_tile_rowptr,
-                                                           const uint32_t *__restrict__ c_mask, int *__restrict__ chunkhist)
+__global__ void __launch_bounds__(256) ex_chunkhist_kernel(const int *__restrict__ chunkptr, const int *__restrict__ chunk_row, int mt,
+                                                           const int *__restrict__ c_tile_rowptr, const uint32_t *__restrict__ c_mask,
+                                                           int *__restrict__ chunkhist)
 {
     const int lane = threadIdx.x & 63;
     const int ch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (ch >= chunkptr[mt]) return;
-    const int i = ex_chunk_row(chunkptr, mt, ch, lane);
+    if (ch >= chunkptr[mt]) return;        // (the grid covers the host's bound on the number of chunks)
+    const int i = chunk_row[ch];
     const int t0 = c_tile_rowptr[i] + ((ch - chunkptr[i]) << 6);
     const int ntl = c_tile_rowptr[i + 1] - t0 < 64 ? c_tile_rowptr[i + 1] - t0 : 64;
     unsigned long long pk[4] = {0, 0, 0, 0};
@@ -1770,32 +1892,57 @@ __global__ void __launch_bounds__(256) ex_chunkhist_kernel(const int *__restrict
     }
 }
 
-__global__ void __launch_bounds__(256) ex_chunkscan_kernel(const int *__restrict__ chunkptr, int mt, int nrows, int *__restrict__ chunkhist,
-                                                           int *__restrict__ rowcnt)
+// one wave per tile row, lane = (chunk of the trip c4, row r): counts -> exclusive bases inside the tile row (in place), and
+// the CSR row pointer of the tile row's sixteen rows
+__global__ void __launch_bounds__(256) ex_chunkscan_kernel(const int *__restrict__ chunkptr, int mt, int nrows, int *chunkhist,
+                                                           const int *__restrict__ c_tile_rowptr, const int *__restrict__ c_tile_nnz_ptr,
+                                                           int *__restrict__ rowptr)
 {
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int r = threadIdx.x & 15;
+    const int lane = threadIdx.x & 63, c4 = lane >> 4, r = lane & 15;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (i >= mt) return;
-    int run = 0;
-    for (int ch = chunkptr[i]; ch < chunkptr[i + 1]; ++ch) {
-        const int h = chunkhist[16 * (size_t)ch + r];
-        chunkhist[16 * (size_t)ch + r] = run;      // in place: count -> exclusive base inside the tile row
-        run += h;
+    const int ch_begin = chunkptr[i], ch_end = chunkptr[i + 1];
+    int carry = 0;
+    for (int ch0 = ch_begin; ch0 < ch_end; ch0 += 4) {
+        const int ch = ch0 + c4;
+        const int h = ch < ch_end ? chunkhist[16 * (size_t)ch + r] : 0;
+        int inc = h;
+        int o = __shfl_up(inc, 16, 64);
+        if (c4 >= 1) inc += o;
+        o = __shfl_up(inc, 32, 64);
+        if (c4 >= 2) inc += o;
+        if (ch < ch_end) chunkhist[16 * (size_t)ch + r] = carry + inc - h;
+        carry += __shfl(inc, 48 + r, 64);
     }
-    if (16 * i + r < nrows) rowcnt[16 * i + r] = run;
+    // carry = entries of row r in this tile row; the tile row's CSR segment starts where its first tile's entries start
+    int pre = carry;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        const int o = __shfl_up(pre, d, 16);
+        if (r >= d) pre += o;
+    }
+    const int seg = c_tile_nnz_ptr[c_tile_rowptr[i]];
+    if (c4 == 0 && 16 * i + r < nrows) rowptr[16 * i + r] = seg + pre - carry;
+    if (i == mt - 1 && lane == 15) rowptr[nrows] = seg + pre;       // closing entry = C_nnz of the slice
 }
 
 template <typename VT>
-__global__ void __launch_bounds__(256) ex_chunkfill_kernel(const int *__restrict__ chunkptr, int mt, int nrows, const int *__restrict__ c_tile_rowptr,
-                                                           const int *__restrict__ c_tile_colidx, const uint32_t *__restrict__ c_mask,
-                                                           const int *__restrict__ c_tile_nnz_ptr, const VT *__restrict__ c_vals,
-                                                           const int *__restrict__ chunkbase, const int *__restrict__ rowptr,
-                                                           int *__restrict__ colidx, VT *__restrict__ vals)
+__global__ void __launch_bounds__(256) ex_chunkfill_kernel(const int *__restrict__ chunkptr, const int *__restrict__ chunk_row, int mt,
+                                                           const int *__restrict__ c_tile_rowptr, const int *__restrict__ c_tile_colidx,
+                                                           const uint32_t *__restrict__ c_mask, const int *__restrict__ c_tile_nnz_ptr,
+                                                           const VT *__restrict__ c_vals, const int *__restrict__ chunkbase,
+                                                           const int *__restrict__ rowptr, int *__restrict__ colidx, VT *__restrict__ vals)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) uint4 s_rp[4 * 64];            // [wave][tile] prefix counts of the tile's rows, a byte each
+    __shared__ __attribute__((aligned(16))) uint4 s_ex[4 * 64 * 2];        // [wave][tile] entries of row r in the chunk's earlier tiles, 16 bits each
+    __shared__ unsigned s_mw[4 * 8 * 64];                                  // [wave][word q][tile]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int ch = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (ch >= chunkptr[mt]) return;
-    const int i = ex_chunk_row(chunkptr, mt, ch, lane);
+    uint4 *const my_rp = s_rp + wv * 64;
+    uint4 *const my_ex = s_ex + wv * 128;
+    unsigned *const my_mw = s_mw + wv * 512;
+    const int i = chunk_row[ch];
     const int t0 = c_tile_rowptr[i] + ((ch - chunkptr[i]) << 6);
     const int ntl = c_tile_rowptr[i + 1] - t0 < 64 ? c_tile_rowptr[i + 1] - t0 : 64;
     const bool live = lane < ntl;
@@ -1805,38 +1952,88 @@ __global__ void __launch_bounds__(256) ex_chunkfill_kernel(const int *__restrict
         M0 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t);
         M1 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t + 4);
     }
-    unsigned long long pk[4], inc[4];
+    const int my_off = live ? c_tile_nnz_ptr[t] : 0x7FFFFFFF;
+    const int e_end = c_tile_nnz_ptr[t0 + ntl];
+    const int cbase = live ? (c_tile_colidx[t] << 4) : 0;
+    // lanes 0..15: where row r of this chunk starts in the CSR arrays
+    int rb = 0;
+    if (lane < 16) rb = rowptr[16 * i + lane] + chunkbase[16 * (size_t)ch + lane];   // (rowptr has 16 * mt + 1 slots; rows past nrows hold no entry)
+    unsigned long long pk[4], ex[4];
     ex_pack_counts(M0, M1, pk);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {          // inclusive scan over the lanes of the packed per-row counts
+    for (int j = 0; j < 4; ++j) {          // exclusive scan over the lanes of the packed per-row counts
         unsigned long long v = pk[j];
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const unsigned long long u = __shfl_up(v, d, 64);
             if (lane >= d) v += u;
         }
-        inc[j] = v;
+        ex[j] = v - pk[j];
     }
-    // lanes 0..15 fetch rowptr + chunk base of row r; every lane picks row r's value by shuffle
-    int rb = 0;
-    if (lane < 16 && 16 * i + lane < nrows) rb = rowptr[16 * i + lane] + chunkbase[16 * (size_t)ch + lane];
     const unsigned w[8] = {M0.x, M0.y, M0.z, M0.w, M1.x, M1.y, M1.z, M1.w};
-    const int cbase = live ? (c_tile_colidx[t] << 4) : 0;
-    int src = live ? c_tile_nnz_ptr[t] : 0;
+    unsigned rp[4] = {0, 0, 0, 0};
+    {
+        int run = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int base_r = __shfl(rb, r, 64);
-        const int excl = (int)(((inc[r >> 2] - pk[r >> 2]) >> (16 * (r & 3))) & 0xFFFFull);
-        int dst = base_r + excl;
-        unsigned m = (r & 1) ? (w[r >> 1] & 0xFFFFu) : (w[r >> 1] >> 16);
-        while (m) {
-            const int c = __builtin_ctz(m);
-            m &= m - 1;
-            colidx[dst] = cbase + c;
-            vals[dst] = c_vals[src];
-            ++dst;
-            ++src;
+        for (int q = 0; q < 8; ++q) {
+            rp[q >> 1] |= (unsigned)run << (16 * (q & 1));
+            run += __popc(w[q] >> 16);
+            rp[q >> 1] |= (unsigned)run << (16 * (q & 1) + 8);
+            run += __popc(w[q] & 0xFFFFu);
         }
+    }
+    my_rp[lane] = make_uint4(rp[0], rp[1], rp[2], rp[3]);
+    my_ex[2 * lane] = make_uint4((unsigned)ex[0], (unsigned)(ex[0] >> 32), (unsigned)ex[1], (unsigned)(ex[1] >> 32));
+    my_ex[2 * lane + 1] = make_uint4((unsigned)ex[2], (unsigned)(ex[2] >> 32), (unsigned)ex[3], (unsigned)(ex[3] >> 32));
+#pragma unroll
+    for (int q = 0; q < 8; ++q) my_mw[q * 64 + lane] = w[q];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned short *const ex16 = reinterpret_cast<const unsigned short *>(my_ex);
+    const int e_begin = __shfl(my_off, 0, 64);
+    for (int ebase = e_begin; ebase < e_end; ebase += 64) {   // wave-uniform trip count
+        const int e = ebase + lane;
+        const bool valid = e < e_end;
+        int ti = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) {
+            const int probe = __shfl(my_off, ti + step, 64);
+            if (probe <= e) ti += step;
+        }
+        const int toff = __shfl(my_off, ti, 64), cb = __shfl(cbase, ti, 64);
+        const unsigned n = valid ? (unsigned)(e - toff) : 0u;
+        const uint4 rp4 = my_rp[ti];
+        const bool h8 = (rp4.z & 0xFFu) <= n;
+        const unsigned d0 = h8 ? rp4.z : rp4.x, d1 = h8 ? rp4.w : rp4.y;
+        const bool h4 = (d1 & 0xFFu) <= n;
+        const unsigned d = h4 ? d1 : d0;
+        const bool h2 = ((d >> 16) & 0xFFu) <= n;
+        const unsigned hh = h2 ? d >> 16 : d & 0xFFFFu;
+        const bool h1 = (hh >> 8) <= n;
+        const int r = (h8 ? 8 : 0) + (h4 ? 4 : 0) + (h2 ? 2 : 0) + (h1 ? 1 : 0);
+        const unsigned k0 = n - (h1 ? hh >> 8 : hh & 0xFFu);            // rank inside the tile's row r
+        const int base_r = __shfl(rb, r, 64);
+        if (!valid) continue;
+        const unsigned word = my_mw[(r >> 1) * 64 + ti];
+        unsigned m = (r & 1) ? word & 0xFFFFu : word >> 16, k = k0;
+        const unsigned t8 = __popc(m & 0xFFu);
+        const bool g8 = k >= t8;
+        k -= g8 ? t8 : 0u;
+        m = g8 ? m >> 8 : m;
+        const unsigned t4 = __popc(m & 0xFu);
+        const bool g4 = k >= t4;
+        k -= g4 ? t4 : 0u;
+        m = g4 ? m >> 4 : m;
+        const unsigned t2 = __popc(m & 3u);
+        const bool g2 = k >= t2;
+        k -= g2 ? t2 : 0u;
+        m = g2 ? m >> 2 : m;
+        const bool g1 = k >= (m & 1u);
+        const int c = (g8 ? 8 : 0) + (g4 ? 4 : 0) + (g2 ? 2 : 0) + (g1 ? 1 : 0);
+        const int dst = base_r + (int)ex16[ti * 16 + r] + (int)k0;
+        colidx[dst] = cb + c;
+        vals[dst] = c_vals[e];
     }
 }
 
@@ -1908,6 +2105,7 @@ extern "C" pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const p
     p->opt_warm = !env_is("PEM_NO_WARM", "1");
     p->opt_export_rows = env_is("PEM_EXPORT", "rows");
     p->opt_s1_serial = getenv("PEM_S1_SERIAL") != nullptr;
+    p->opt_decode = !env_is("PEM_S3_DECODE", "0");
     *out = p;
     return PEM_OK;
 }
@@ -1949,6 +2147,7 @@ static int *plan_option_slot(pem_cplan *p, pem_option which)
     case PEM_OPT_S1_XLCAP: return &p->opt_xlcap;
     case PEM_OPT_EXPORT_ROWS: return &p->opt_export_rows;
     case PEM_OPT_S1_SERIAL: return &p->opt_s1_serial;
+    case PEM_OPT_S3_DECODE: return &p->opt_decode;
     default: return nullptr;
     }
 }
@@ -2369,6 +2568,8 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
     const bool fused = p->pairs_ready && p->opt_wide;
     p->wide = fused;
     p->verify_folded = false;
+    p->s3_decode = false;
+    p->c_rowcolidx_valid = false;
     int64_t nnzc = 0;
     if (fused) {
         PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
@@ -2382,10 +2583,18 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
             if (!p->group_nnz_cleared) PEM_HIP(hipMemsetAsync(p->group_nnz.p, 0, sizeof(int) * (ngroups + 4), st));
             p->group_nnz_cleared = false;
             int *group_nnz = p->group_nnz.as<int>();
+            // Shallow plans (fewer than two pairs per C tile) read an entry's (row, column) off the mask in step 3, so the pass
+            // needs no (r<<4|c) bytes: offsets come from 2-byte entry counts and Ctiles_rowColIdx is materialised on demand.
+            // Deep plans keep the bytes: their many-pair kernel walks a tile's entries 64 at a time and the bytes are a small
+            // part of their traffic.
+            const bool deep = p->npairs >= 2 * p->ntiles_c;
+            const bool decode = p->opt_decode && !deep;
+            p->s3_decode = decode;
+            if (decode) PEM_TRY(p->c_tile_cnt.reserve(sizeof(uint16_t) * (ntc + 8)));
             PEM_LAUNCH(ctx, s2_tiles_kernel, (unsigned)nblk, 256, p->scratch_col.as<int>(), p->scratch_off.as<int>(), (long long)n,
                        p->block_info.as<int2>(), p->c_tile_rowptr.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), A->masks.as<uint16_t>(),
                        B->masks.as<uint16_t>(), (long long)ntc, p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>(), p->c_mask.as<uint32_t>(),
-                       group_nnz);
+                       group_nnz, decode ? p->c_tile_cnt.as<uint16_t>() : (uint16_t *)nullptr);
             PEM_TRY(exclusive_scan_i32(ctx, group_nnz, group_nnz, ngroups, ctx->d_scalars + 2));
             if (p->warm_pass) {
                 nnzc = p->w_nnz;
@@ -2402,20 +2611,30 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
                 nnzc = sc[0];
             }
             // sizing phase "C entries"
-            PEM_TRY(arena_phase(ctx->arena, {{&p->c_rowcolidx, (size_t)nnzc + 16}, {&p->s3_chunk_tile, sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)},
+            PEM_TRY(arena_phase(ctx->arena, {{&p->c_rowcolidx, decode ? (size_t)0 : (size_t)nnzc + 16},
+                                             {&p->s3_chunk_tile, sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)},
                                              {&p->c_vals, (size_t)A->value_bytes * ((size_t)nnzc + 1)}}));
-            PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
             PEM_TRY(p->s3_chunk_tile.reserve(sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)));
             WarmCheck wc = {};
             if (p->warm_pass) wc = WarmCheck{1, p->w_P, p->w_Pall, p->w_TC, p->w_nnz, p->w_nxl, p->w_counts[0], p->w_counts[1], p->w_counts[2], p->w_counts[3]};
             p->verify_folded = p->warm_pass;
-            PEM_LAUNCH(ctx, s2_entries_kernel, (unsigned)((ntc + S2_GROUP) / S2_GROUP), S2_GROUP, p->c_mask.as<uint32_t>(), (long long)ntc, group_nnz,
-                       (long long)nnzc, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->s3_chunk_tile.as<int>(), ctx->d_flags, wc,
-                       reinterpret_cast<const long long *>(ctx->d_scalars), p->bin_count.as<int>());
+            if (decode) {
+                PEM_LAUNCH(ctx, s2_offsets_kernel, grid_for(((ntc + S2_GROUP) / S2_GROUP) * 64, 256), 256, p->c_tile_cnt.as<uint16_t>(), (long long)ntc,
+                           group_nnz, p->c_tile_nnz_ptr.as<int>(), p->s3_chunk_tile.as<int>(), ctx->d_flags, wc,
+                           reinterpret_cast<const long long *>(ctx->d_scalars), p->bin_count.as<int>());
+                p->c_rowcolidx_valid = false;
+            } else {
+                PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
+                PEM_LAUNCH(ctx, s2_entries_kernel, (unsigned)((ntc + S2_GROUP) / S2_GROUP), S2_GROUP, p->c_mask.as<uint32_t>(), (long long)ntc, group_nnz,
+                           (long long)nnzc, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->s3_chunk_tile.as<int>(), ctx->d_flags, wc,
+                           reinterpret_cast<const long long *>(ctx->d_scalars), p->bin_count.as<int>());
+                p->c_rowcolidx_valid = true;
+            }
             p->compact_valid = true;
         } else {
             PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_nnz_ptr.as<int>(), p->c_tile_nnz_ptr.as<int>(), 0, ctx->d_scalars + 2));
             p->compact_valid = true;   // pairs_offset[0] = 0 was set by step 1's reset
+            p->c_rowcolidx_valid = true;
         }
     } else {
         PEM_TRY(ensure_compact(ctx, p));
@@ -2444,7 +2663,10 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
         p->w_nnz = nnzc;
     }
     p->nnz_c = nnzc;
-    PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
+    if (!(fused && p->s3_decode)) {
+        PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
+        p->c_rowcolidx_valid = fused;       // (the baseline kernels below fill it)
+    }
     PEM_TRY(p->s3_chunk_tile.reserve(sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)));
     PEM_TRY(p->c_vals.reserve((size_t)A->value_bytes * ((size_t)nnzc + 1)));
     if (ntc > 0 && !fused) {   // the 16-lanes-per-tile baseline writes Ctiles_rowPtr as it goes, like the reference (spgemm.cu:579-580)
@@ -2452,6 +2674,7 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_LAUNCH(ctx, s2_crowcol_kernel, grid_for(ntc * 16, 256), 256, p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
                    p->c_rowptr.as<uint8_t>(), p->c_rowcolidx.as<uint8_t>());
         p->c_rowptr_valid = true;
+        p->c_rowcolidx_valid = true;
     }
     if (!ctx->capturing) PEM_HIP(hipEventRecord(ctx->ev[3], st));
     p->state = 2;
@@ -2475,13 +2698,19 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
                      p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),       \
                      (long long)p->nnz_c, p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),       \
                      A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                  \
-                     p->s3_chunk_tile.as<int>())
+                     p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>())
+#define PEM_S3_DECODE(VT, NAME)                                                                                                                \
+    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, false, false, true>), grid_for(((size_t)p->nnz_c + S3_EPW - 1) / S3_EPW * 64, 256), 256, \
+                     p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),       \
+                     (long long)p->nnz_c, (const uint8_t *)nullptr, p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),           \
+                     A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                  \
+                     p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>())
 #define PEM_S3_WIDE3(VT, NAME)                                                                                                                 \
     PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, true, true>), grid_for(((size_t)p->nnz_c + S3_EPW - 1) / S3_EPW * 64, 256), 256, \
                      p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),       \
                      (long long)p->nnz_c, p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),       \
                      A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                  \
-                     p->s3_chunk_tile.as<int>())
+                     p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>())
 #define PEM_S3_LAUNCH(VT)                                                                                                                      \
     do {                                                                                                                                       \
         if (wide && deep && p->opt_band) {                                                                                                     \
@@ -2492,6 +2721,8 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
                              A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>());         \
         } else if (wide && deep)                                                                                                               \
             PEM_S3_WIDE(VT, true, "s3_accumulate_wide_kernel<" #VT ",deep>");                                                                  \
+        else if (wide && p->s3_decode)                                                                                                         \
+            PEM_S3_DECODE(VT, "s3_accumulate_wide_kernel<" #VT ",decode>");                                                                    \
         else if (wide)                                                                                                                         \
             PEM_S3_WIDE(VT, false, "s3_accumulate_wide_kernel<" #VT ">");                                                                      \
         else                                                                                                                                   \
@@ -2508,6 +2739,7 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
 #undef PEM_S3_LAUNCH
 #undef PEM_S3_WIDE
 #undef PEM_S3_WIDE3
+#undef PEM_S3_DECODE
     if (!ctx->capturing) PEM_HIP(hipEventRecord(ctx->ev[5], st));
     p->state = 3;
     return PEM_OK;
@@ -2673,6 +2905,25 @@ static pem_status ensure_c_rowptr(pem_ctx *ctx, const pem_cplan *p)
     return PEM_OK;
 }
 
+// Ctiles_rowColIdx on demand (plans whose step 3 reads the masks): the entry kernel of the other plans, run once -- it
+// recomputes the same offsets from the same scanned group counts and emits the bytes
+static pem_status ensure_c_rowcolidx(pem_ctx *ctx, const pem_cplan *cp)
+{
+    pem_cplan *p = const_cast<pem_cplan *>(cp);
+    if (p->c_rowcolidx_valid || p->state < 2) return PEM_OK;
+    const size_t ntc = (size_t)p->ntiles_c;
+    PEM_ENTER(ctx);
+    PEM_TRY(p->c_rowcolidx.reserve((size_t)p->nnz_c + 16));
+    if (ntc > 0) {
+        WarmCheck wc = {};
+        PEM_LAUNCH(ctx, s2_entries_kernel, (unsigned)((ntc + S2_GROUP) / S2_GROUP), S2_GROUP, p->c_mask.as<uint32_t>(), (long long)ntc,
+                   p->group_nnz.as<int>(), (long long)p->nnz_c, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->s3_chunk_tile.as<int>(),
+                   ctx->d_flags, wc, reinterpret_cast<const long long *>(ctx->d_scalars), p->bin_count.as<int>());
+    }
+    p->c_rowcolidx_valid = true;
+    return PEM_OK;
+}
+
 extern "C" pem_status pem_cplan_get_array(pem_ctx *ctx, const pem_cplan *p, pem_cplan_array which, void *host_dst, int64_t bytes)
 {
     if (!ctx || !p || (!host_dst && bytes > 0)) return PEM_E_INVALID;
@@ -2707,7 +2958,12 @@ extern "C" pem_status pem_cplan_get_array(pem_ctx *ctx, const pem_cplan *p, pem_
         want = 16 * TC;
         need = 2;
         break;
-    case PEM_C_ROWCOLIDX: src = p->c_rowcolidx.p; want = NZ; need = 2; break;
+    case PEM_C_ROWCOLIDX:
+        PEM_TRY(ensure_c_rowcolidx(ctx, p));
+        src = p->c_rowcolidx.p;
+        want = NZ;
+        need = 2;
+        break;
     case PEM_C_VALS: src = p->c_vals.p; want = (size_t)p->A->value_bytes * NZ; need = 3; break;   // native type
     default: set_error("unknown pem_cplan_array %d", (int)which); return PEM_E_INVALID;
     }
@@ -2763,20 +3019,34 @@ static pem_status export_csr_device_impl(pem_ctx *ctx, const pem_cplan *p, int32
                        d_rowptr, d_colidx, d_vals);
     } else if (mt > 0 && nrows > 0) {
         const size_t maxchunks = (size_t)p->ntiles_c / 64 + (size_t)mt + 1;   // every tile row adds at most one partial chunk
-        DevBuf &chunkptr = ctx->tmp[4], &chunkhist = ctx->tmp[5];
+        DevBuf &chunkptr = ctx->tmp[4], &chunkhist = ctx->tmp[5], &chunkrow = ctx->tmp[6], &rp16 = ctx->tmp[7];
+        PEM_TRY(arena_phase(ctx->arena, {{&chunkptr, sizeof(int) * ((size_t)mt + 4)}, {&chunkhist, sizeof(int) * 16 * (maxchunks + 1)},
+                                         {&chunkrow, sizeof(int) * (maxchunks + 4)}, {&rp16, sizeof(int) * (16 * (size_t)mt + 4)}}));
         PEM_TRY(chunkptr.reserve(sizeof(int) * ((size_t)mt + 4)));
         PEM_TRY(chunkhist.reserve(sizeof(int) * 16 * (maxchunks + 1)));
+        PEM_TRY(chunkrow.reserve(sizeof(int) * (maxchunks + 4)));
         PEM_LAUNCH(ctx, ex_chunkcount_kernel, grid_for((size_t)mt, 256), 256, p->c_tile_rowptr.as<int>(), mt, chunkptr.as<int>());
         PEM_TRY(exclusive_scan_i32(ctx, chunkptr.as<int>(), chunkptr.as<int>(), (size_t)mt, nullptr));
-        if (p->ntiles_c > 0)
-            PEM_LAUNCH(ctx, ex_chunkhist_kernel, grid_for(maxchunks * 64, 256), 256, chunkptr.as<int>(), mt, p->c_tile_rowptr.as<int>(),
-                       p->c_mask.as<uint32_t>(), chunkhist.as<int>());
-        PEM_LAUNCH(ctx, ex_chunkscan_kernel, grid_for((size_t)mt * 16, 256), 256, chunkptr.as<int>(), mt, nrows, chunkhist.as<int>(), d_rowptr);
-        PEM_TRY(exclusive_scan_i32(ctx, d_rowptr, d_rowptr, (size_t)nrows, nullptr));
-        if (p->nnz_c > 0)
-            PEM_LAUNCH(ctx, ex_chunkfill_kernel<VT>, grid_for(maxchunks * 64, 256), 256, chunkptr.as<int>(), mt, nrows, p->c_tile_rowptr.as<int>(),
-                       p->c_tile_colidx.as<int>(), p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>(), p->c_vals.as<VT>(), chunkhist.as<int>(),
-                       d_rowptr, d_colidx, d_vals);
+        // (the number of chunks is only known on the device: the grids cover the bound, waves past the end leave at once)
+        if (p->ntiles_c > 0 && p->nnz_c > 0) {
+            // the row pointer is written in slots of sixteen per tile row; the caller's array ends at nrows + 1, which the last
+            // tile row may fall short of filling -- so a slice whose row count is no multiple of 16 goes through a padded copy
+            int *rp = d_rowptr;
+            const bool padded = nrows != 16 * mt;
+            if (padded) {
+                PEM_TRY(rp16.reserve(sizeof(int) * (16 * (size_t)mt + 4)));
+                rp = rp16.as<int>();
+            }
+            PEM_LAUNCH(ctx, ex_chunkrow_kernel, grid_for((size_t)mt * 64, 256), 256, chunkptr.as<int>(), mt, chunkrow.as<int>());
+            PEM_LAUNCH(ctx, ex_chunkhist_kernel, grid_for(maxchunks * 64, 256), 256, chunkptr.as<int>(), chunkrow.as<int>(), mt,
+                       p->c_tile_rowptr.as<int>(), p->c_mask.as<uint32_t>(), chunkhist.as<int>());
+            PEM_LAUNCH(ctx, ex_chunkscan_kernel, grid_for((size_t)mt * 64, 256), 256, chunkptr.as<int>(), mt, padded ? 16 * mt : nrows, chunkhist.as<int>(),
+                       p->c_tile_rowptr.as<int>(), p->c_tile_nnz_ptr.as<int>(), rp);
+            PEM_LAUNCH(ctx, ex_chunkfill_kernel<VT>, grid_for(maxchunks * 64, 256), 256, chunkptr.as<int>(), chunkrow.as<int>(), mt,
+                       p->c_tile_rowptr.as<int>(), p->c_tile_colidx.as<int>(), p->c_mask.as<uint32_t>(), p->c_tile_nnz_ptr.as<int>(),
+                       p->c_vals.as<VT>(), chunkhist.as<int>(), rp, d_colidx, d_vals);
+            if (padded) PEM_HIP(hipMemcpyAsync(d_rowptr, rp, sizeof(int) * ((size_t)nrows + 1), hipMemcpyDeviceToDevice, st));
+        }
     }
     PEM_HIP(hipEventRecord(ctx->ev[7], st));
     return PEM_OK;
