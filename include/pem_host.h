@@ -24,6 +24,14 @@ int pem_mm_read(const char *path, int threads, pem_coo *out);
 void pem_coo_free(pem_coo *m);
 const char *pem_host_last_error(void);
 
+/* Seeded synthetic stand-ins for the SuiteSparse inputs BASELINE.json names (no SuiteSparse file exists
+ * offline; "generator in C++, fixed seeds, values uniform in [-1,1) excluding 0, no duplicates, sorted rows").
+ * name: one of pem_standin_names() ("cage4 scircuit webbase-1M mc2depi cage15"); scale in (0, 1] shrinks rows and
+ * nnz together (tests).  The triplets come out sorted by (row, column); free with pem_coo_free.
+ * 0 ok, -1 bad argument, -2 unknown name, -6 out of memory.  Models and calibration: host/standin.cpp. */
+int pem_standin_generate(const char *name, double scale, pem_coo *out);
+const char *pem_standin_names(void);
+
 /* spgemm.cu:1527-1560: <dir>/SPGEMM_RESULT_{NNZ,ROWS,COLS,VALS}.txt -- NNZ one integer without
  * newline, ROWS/COLS one 0-based int per line, VALS fixed with 17 digits after the point. */
 int pem_write_result_files(const char *dir, int64_t nnz, const int32_t *rows, const int32_t *cols, const double *vals);

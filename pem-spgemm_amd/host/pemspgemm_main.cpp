@@ -210,6 +210,20 @@ static int run_multi(int ngpu, const pem_coo &ca, const pem_coo *cb, bool aat, b
     return rc;
 }
 
+// the input: a Matrix-Market file (spgemm.cu:43-110), or "standin:NAME" for the seeded generator (--standin)
+static double g_standin_scale = 1.0;
+static int read_input(const char *path, pem_coo *out)
+{
+    if (!strncmp(path, "standin:", 8)) {
+        const int rc = pem_standin_generate(path + 8, g_standin_scale, out);
+        if (rc != 0) fprintf(stderr, "pemspgemm: --standin %s (scale %g): no such stand-in (have: %s) or bad scale\n", path + 8, g_standin_scale, pem_standin_names());
+        return rc;
+    }
+    const int rc = pem_mm_read(path, 0, out);
+    if (rc != 0) fprintf(stderr, "pemspgemm: %s\n", pem_host_last_error());
+    return rc;
+}
+
 int main(int argc, char *argv[])
 {
     // Beyond the reference: `--B <file.mtx>` multiplies by a second matrix instead of A itself,
@@ -218,13 +232,19 @@ int main(int argc, char *argv[])
     // (size + mtime), loads it instead of parsing and converting.
     // `--fp32` computes in float: the values are rounded once at conversion, step 3 runs one fmaf per product.
     // `--gpus N`: N tile-row blocks of A on N devices, C gathered to device 0 over RCCL (see run_multi).
-    const char *b_path = nullptr, *out_path = nullptr, *cache_dir = nullptr;
+    // `--standin NAME [--scale S]`: the seeded C++ stand-in generator takes the place of the file (no SuiteSparse
+    // file exists offline); NAME then stands where the path stood, and the remaining positional arguments keep their meaning.
+    const char *b_path = nullptr, *out_path = nullptr, *cache_dir = nullptr, *standin = nullptr;
+    static std::string standin_path;
+    static std::vector<char *> argv_store;
     bool fp32 = false;
     int ngpu = 0;   // 0: the reference's single-device path
     {
         int w = 1;
         for (int r = 1; r < argc; ++r) {
             if (!strcmp(argv[r], "--B") && r + 1 < argc) b_path = argv[++r];
+            else if (!strcmp(argv[r], "--standin") && r + 1 < argc) standin = argv[++r];
+            else if (!strcmp(argv[r], "--scale") && r + 1 < argc) g_standin_scale = atof(argv[++r]);
             else if (!strcmp(argv[r], "--gpus") && r + 1 < argc) ngpu = atoi(argv[++r]);
             else if (!strcmp(argv[r], "--out") && r + 1 < argc) out_path = argv[++r];
             else if (!strcmp(argv[r], "--cache") && r + 1 < argc) cache_dir = argv[++r];
@@ -232,6 +252,13 @@ int main(int argc, char *argv[])
             else argv[w++] = argv[r];
         }
         argc = w;
+        if (standin) {
+            standin_path = std::string("standin:") + standin;
+            argv_store.assign(argv, argv + argc);
+            argv_store.insert(argv_store.begin() + 1, const_cast<char *>(standin_path.c_str()));
+            argv = argv_store.data();
+            ++argc;
+        }
     }
     if (argc <= 1 || argc > 4) {   // spgemm.cu:722-725
         printf("Provide a matrix market file path. Exiting.\n");
@@ -252,10 +279,7 @@ int main(int argc, char *argv[])
         pem_coo ca, cb;
         memset(&ca, 0, sizeof ca);
         memset(&cb, 0, sizeof cb);
-        if (pem_mm_read(argv[1], 0, &ca) != 0 || (b_path && pem_mm_read(b_path, 0, &cb) != 0)) {
-            fprintf(stderr, "pemspgemm: %s\n", pem_host_last_error());
-            return 1;
-        }
+        if (read_input(argv[1], &ca) != 0 || (b_path && read_input(b_path, &cb) != 0)) return 1;
         if (!b_path && !aat && ca.rows != ca.cols) {
             printf("input is rectangular. Only AAt is possible. Exiting.\n");   // spgemm.cu:782-786
             return 1;
@@ -370,10 +394,7 @@ int main(int argc, char *argv[])
             }
         }
         if (!src.read) {
-            if (pem_mm_read(src.path, 0, &src.coo) != 0) {
-                fprintf(stderr, "pemspgemm: %s\n", pem_host_last_error());
-                return 1;
-            }
+            if (read_input(src.path, &src.coo) != 0) return 1;
             src.read = true;
         }
         const pem_coo &m = src.coo;

@@ -10,7 +10,8 @@ LIB_PATH = os.path.join(_HERE, "libpemhost.so")
 MGPU_LIB_PATH = os.path.join(_HERE, "libpemmgpu.so")   # include/pem_mgpu.h: contexts of one process over several GPUs + RCCL gather
 CLI_PATH = os.path.join(_HERE, "pemspgemm")
 
-HOST_SYMBOLS = ["pem_mm_read", "pem_coo_free", "pem_host_last_error", "pem_write_result_files", "pem_csv_append", "pem_write_mtx_csr"]
+HOST_SYMBOLS = ["pem_mm_read", "pem_coo_free", "pem_host_last_error", "pem_write_result_files", "pem_csv_append", "pem_write_mtx_csr",
+                "pem_standin_generate", "pem_standin_names"]
 
 
 class _Coo(C.Structure):
@@ -86,6 +87,26 @@ def mm_read(path, threads=0):
                symmetric=bool(m.symmetric), field=m.field)
     lib().pem_coo_free(C.byref(m))
     return out
+
+
+def standin(name, scale=1.0):
+    """pem_standin_generate: the seeded C++ stand-in generator behind `pemspgemm --standin` -> rows, cols, I, J, V"""
+    m = _Coo()
+    rc = lib().pem_standin_generate(name.encode(), C.c_double(float(scale)), C.byref(m))
+    if rc != 0:
+        raise RuntimeError(f"pem_standin_generate({name!r}, {scale}) -> {rc}")
+    n = int(m.nnz)
+    I = np.ctypeslib.as_array(m.I, shape=(n,)).astype(np.int32, copy=True)
+    J = np.ctypeslib.as_array(m.J, shape=(n,)).astype(np.int32, copy=True)
+    V = np.ctypeslib.as_array(m.V, shape=(n,)).astype(np.float64, copy=True)
+    rows, cols = m.rows, m.cols
+    lib().pem_coo_free(C.byref(m))
+    return rows, cols, I, J, V
+
+
+def standin_names():
+    lib().pem_standin_names.restype = C.c_char_p
+    return lib().pem_standin_names().decode().split()
 
 
 def write_result_files(directory, rows, cols, vals):
