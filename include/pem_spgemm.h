@@ -169,6 +169,10 @@ typedef enum {
     PEM_OPT_S1_XLCAP = 6,           /* test hook: tile rows with more live products take the global path (0: off)              */
     PEM_OPT_EXPORT_ROWS = 7,        /* 0 (default): balanced chunk export; 1: 16 lanes per tile row (A/B baseline)             */
     PEM_OPT_S1_SERIAL = 8,          /* diagnostic: step 1's row bins one after the other instead of concurrently               */
+    PEM_OPT_S1_XL_GLOBAL = 10,      /* 0 (default): tile rows beyond the LDS bins are sorted one workgroup per row where their products
+                                       lie; 1: all of them through one global radix sort on (row, tile column) (rows above 2^18 live
+                                       products always)                                                                              */
+    PEM_OPT_S3_EPW = 11,            /* step 3: C entries per wave / 256 (0, default: 1, or 4 where C tiles hold 8+ entries on average) */
     PEM_OPT_S3_DECODE = 9           /* 1 (default): on plans with < 2 pairs per C tile step 3 reads (row, column) off the C masks and
                                        Ctiles_rowColIdx is materialised on demand; 0: step 2 writes it on every pass               */
 } pem_option;

@@ -196,8 +196,8 @@ struct pem_ctx {
     // timing
     hipEvent_t ev[8] = {};             // step spans
     // fork/join inside a step: an independent long-tailed kernel runs on an auxiliary stream
-    hipStream_t aux[3] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {};
+    hipStream_t aux[4] = {};           // [0..2]: step 1's row bins; [3]: its oversized-row chain
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {};
     pem_timings timings = {};
     bool profiling = false;
     std::vector<pem::KernelStat> stats;
@@ -289,6 +289,8 @@ struct pem_cplan {
     int opt_prune = 1, opt_key64 = 0, opt_xlcap = 0;
     int opt_band = 1;                                  // 0: many-pair tiles stay in the entry-per-lane kernel
     int opt_step1_esc = 0, opt_wide = 1, opt_warm = 1, opt_export_rows = 0, opt_s1_serial = 0;
+    int opt_xl_global = 0;                             // oversized rows: the global (row, tile column) radix sort instead of one workgroup per row
+    int opt_epw = 0;                                   // step 3: entries per wave / 256 (0: chosen from the C tiles' density)
     int opt_decode = 1;                                // shallow plans: step 3 reads (row, column) off the C masks, no Ctiles_rowColIdx on the pass
     int64_t ntiles_c = 0, npairs = 0, nnz_c = 0;
     pem::DevBuf c_tile_rowptr, c_tile_colidx;
@@ -330,5 +332,5 @@ struct pem_cplan {
     int64_t w_P = 0, w_Pall = 0, w_TC = 0, w_nnz = 0;
     int w_counts[4] = {0, 0, 0, 0};
     int64_t w_nxl = 0;
-    int w_nrows_xl = 0;
+    int w_nrows_xl = 0, w_max_xl = 0;
 };

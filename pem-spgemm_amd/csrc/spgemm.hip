@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) s1_xl_expand_kernel(const long long *__re
                                                            const int *__restrict__ b_tile_rowptr, const int *__restrict__ b_tile_colidx,
                                                            const uint32_t *__restrict__ b_occ, int prune, int bits_tc,
                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, int *__restrict__ prod_a,
-                                                           int *__restrict__ prod_b)
+                                                           int *__restrict__ prod_b, int local_keys)
 {
     const int arel = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int l = threadIdx.x & 15, grp = (threadIdx.x & 63) >> 4;
@@ -144,27 +144,54 @@ __global__ void __launch_bounds__(256) s1_xl_expand_kernel(const long long *__re
             if (prune) acol = a_occ[a] & 0xFFFFu;
         }
     }
-    // the four 16-lane groups of a wave walk different B rows: iterate to the longest, compact per group
-    int maxlen = len;
+    // the four 16-lane groups of a wave walk different B rows: iterate to the longest, compact per group.  A B tile row of
+    // 256+ tiles (a directory page of webbase-1M: 4 700) is left out of that walk -- sixteen lanes took 294 dependent trips
+    // over it and the whole grid waited (121 us for 1.6 M products) -- and walked by the whole wave afterwards.
+    constexpr int XL_LONG = 256;
+    const bool is_long = len >= XL_LONG;
+    const int glen = is_long ? 0 : len;
+    int maxlen = glen;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         const int o = __shfl_xor(maxlen, d, 64);
         maxlen = o > maxlen ? o : maxlen;
     }
     const uint64_t hi = (uint64_t)(unsigned)i << bits_tc;
+    auto emit_product = [&](const int x, const int row_hi_src, const int aa, const int bb) {
+        const uint64_t hh = (uint64_t)(unsigned)row_hi_src << bits_tc;
+        const unsigned col = (unsigned)b_tile_colidx[bb];
+        keys[x] = local_keys ? ((uint64_t)col << 32) | (uint64_t)(unsigned)x : hh | (uint64_t)col;
+        perm[x] = (uint32_t)x;
+        prod_a[x] = aa;
+        prod_b[x] = bb;
+    };
+    (void)hi;
     int run = 0;
     for (int q0 = 0; q0 < maxlen; q0 += 16) {
         const int q = q0 + l;
-        const bool live = q < len && (!prune || (acol & (b_occ[b0 + q] >> 16)) != 0);
+        const bool live = q < glen && (!prune || (acol & (b_occ[b0 + q] >> 16)) != 0);
         const unsigned m16 = (unsigned)(__ballot(live) >> (16 * grp)) & 0xFFFFu;
-        if (live) {
-            const int x = x0 + run + __popc(m16 & ((1u << l) - 1u));
-            keys[x] = hi | (uint64_t)(unsigned)b_tile_colidx[b0 + q];
-            perm[x] = (uint32_t)x;
-            prod_a[x] = a;
-            prod_b[x] = b0 + q;
-        }
+        // (keys: local_keys -> (tile column, position) for the per-row sort of s1_xl_rowsort_kernel -- a row's products already
+        // sit in the row's own stretch of the buffers, in product order; else (row, tile column) for the global sort)
+        if (live) emit_product(x0 + run + __popc(m16 & ((1u << l) - 1u)), i, a, b0 + q);
         run += __popc(m16);
+    }
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned long long todo = __ballot(l == 0 && is_long && x0 >= 0);
+    while (todo) {                                              // wave-uniform
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int ha = __shfl(a, src, 64), hb0 = __shfl(b0, src, 64), hlen = __shfl(len, src, 64), hx0 = __shfl(x0, src, 64), hrow = __shfl(i, src, 64);
+        const unsigned hcol = (unsigned)__shfl((int)acol, src, 64);
+        int hrun = 0;
+        for (int q0 = 0; q0 < hlen; q0 += 64) {
+            const int q = q0 + lane;
+            const bool live = q < hlen && (!prune || (hcol & (b_occ[hb0 + q] >> 16)) != 0);
+            const unsigned long long bal = __ballot(live);
+            if (live) emit_product(hx0 + hrun + __popcll(bal & lt), hrow, ha, hb0 + q);
+            hrun += __popcll(bal);
+        }
     }
 }
 
@@ -297,7 +324,10 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
     if (threadIdx.x == 0 && blk_all) atomicAdd(reinterpret_cast<unsigned long long *>(&scalars[3]), (unsigned long long)blk_all);
     __syncthreads();
     if (bin >= 0) row_list[(size_t)bin * mt + blk_base[bin] + wbase + rank] = i;
-    if (bin == 4) xl_base[i] = atomicAdd(&bin_count[5], nl);   // oversized rows are few
+    if (bin == 4) {                                             // oversized rows are few
+        xl_base[i] = atomicAdd(&bin_count[5], nl);
+        atomicMax(&bin_count[6], nl);                           // the largest of them decides between the per-row and the global sort
+    }
 }
 
 // oversized rows (global path): live-product offsets of the row's A tiles relative to the row, one block per row
@@ -908,6 +938,137 @@ __global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint3
     if (s == 0) row_tc[i] = ntiles_row;
 }
 
+// Oversized rows, one workgroup per row.  The global path above sorts all oversized rows' products together: four radix
+// passes over (row, tile column) keys, each a histogram launch, a scan and a scatter launch, then heads, a scan, row starts and
+// the emit -- nineteen launches for what is, on webbase-1M, forty tile rows of ~40 k products (its directory pages: a row of
+// 4 700 A tiles fits no LDS table): 0.3 ms of launch latency on the critical path of a 1.1 ms pass.  But s1_xl_expand_kernel
+// has already put every such row's live products into the row's OWN stretch of the key buffer, in product order.  So each row
+// is sorted where it lies by one 1024-thread workgroup: a stable LSD radix sort on the tile-column bits with the keys in
+// global memory (L2-resident: a row is a few hundred KB) -- per-wave digit histograms in LDS, one scan of the 16 x 256
+// counters, ballot-ranked scatter, as in the 16-wave LDS bins -- followed by the same emit as s1_rowsort_kernel.  One launch.
+constexpr int S1_XLL_MAX = 1 << 18;     // rows with more live products than this keep the global path (one workgroup would take too long)
+__global__ void __launch_bounds__(1024) s1_xl_rowsort_kernel(const int *__restrict__ xl_rows, int nrows_xl, const int *__restrict__ xl_base,
+                                                             const int *__restrict__ row_lbase, uint64_t *k0, uint64_t *k1, int bits_tc,
+                                                             const int *__restrict__ prod_a, const int *__restrict__ prod_b,
+                                                             int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ scratch_col,
+                                                             int *__restrict__ scratch_off, int2 *__restrict__ block_info, int *__restrict__ row_tc)
+{
+    constexpr int WAVES = 16;
+    __shared__ unsigned hist[WAVES * 256];
+    __shared__ int wsum[WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned *myhist = hist + wave * 256;
+    for (int li = blockIdx.x; li < nrows_xl; li += gridDim.x) {
+        const int i = xl_rows[li];
+        const int base = xl_base[i], lp0 = row_lbase[i], n = row_lbase[i + 1] - lp0;
+        uint64_t *src = k0 + base, *dst = k1 + base;
+        const int per = (((n + WAVES - 1) / WAVES) + 63) & ~63;      // every wave sorts one contiguous stretch: wave order = product order
+        const int w0 = wave * per, w1 = w0 + per < n ? w0 + per : n;
+        for (int shift = 32; shift < 32 + bits_tc; shift += 8) {
+            for (int x = tid; x < WAVES * 256; x += 1024) hist[x] = 0;
+            __syncthreads();
+            for (int x = w0 + lane; x < w1; x += 64) atomicAdd(&myhist[(unsigned)(src[x] >> shift) & 255u], 1u);
+            __syncthreads();
+            {   // exclusive scan over (digit, wave): thread t owns digit t>>2, waves 4(t&3) .. 4(t&3)+3
+                const int d = tid >> 2, wq = (tid & 3) * 4;
+                unsigned v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = hist[(wq + j) * 256 + d];
+                const int tsum = (int)(v[0] + v[1] + v[2] + v[3]);
+                int inc = tsum;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    const int o = __shfl_up(inc, dd, 64);
+                    if (lane >= dd) inc += o;
+                }
+                if (lane == 63) wsum[wave] = inc;
+                __syncthreads();
+                int ex = inc - tsum;
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w)
+                    if (w < wave) ex += wsum[w];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    hist[(wq + j) * 256 + d] = (unsigned)ex;
+                    ex += (int)v[j];
+                }
+            }
+            __syncthreads();
+            for (int x0 = w0; x0 < w1; x0 += 64) {                   // (wave-uniform trip count)
+                const int x = x0 + lane;
+                const bool valid = x < w1;
+                const uint64_t key = valid ? src[x] : 0ull;
+                const unsigned d = (unsigned)(key >> shift) & 255u;
+                unsigned long long m = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const bool bit = (d >> b) & 1u;
+                    const unsigned long long bal = __ballot(bit);
+                    m &= bit ? bal : ~bal;
+                }
+                if (valid) {
+                    const unsigned pos = myhist[d];
+                    const int rank = __popcll(m & lt);
+                    dst[pos + rank] = key;
+                    if (rank == 0) myhist[d] = pos + (unsigned)__popcll(m);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __threadfence_block();
+            __syncthreads();
+            uint64_t *t = src;
+            src = dst;
+            dst = t;
+        }
+        // emit (as s1_rowsort_kernel): sorted pairs, and per distinct tile column its column + first pair into the row's slots
+        int tiles = 0;
+        for (int s0 = 0; s0 < n; s0 += 1024) {
+            const int sidx = s0 + tid;
+            const bool valid = sidx < n;
+            int j = 0, a = 0, b = 0;
+            bool head = false;
+            if (valid) {
+                const uint64_t key = src[sidx];
+                j = (int)(key >> 32);
+                const unsigned x = (unsigned)(key & 0xFFFFFFFFull);
+                head = sidx == 0 || (int)(src[sidx - 1] >> 32) != j;
+                a = prod_a[x];
+                b = prod_b[x];
+            }
+            const unsigned long long bal = __ballot(head);
+            if (lane == 0) wsum[wave] = __popcll(bal);
+            __syncthreads();
+            int woff = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const int c = wsum[w];
+                if (w < wave) woff += c;
+                tot += c;
+            }
+            if (valid) {
+                pairs_a[lp0 + sidx] = a;
+                pairs_b[lp0 + sidx] = b;
+                if (head) {
+                    const int rank = tiles + woff + __popcll(bal & lt);
+                    scratch_col[lp0 + rank] = j;
+                    scratch_off[lp0 + rank] = lp0 + sidx;
+                }
+            }
+            tiles += tot;
+            __syncthreads();
+        }
+        for (int x = tiles + tid; x < n; x += 1024) {               // the row's slots behind its last tile (see s1_rowsort_kernel)
+            scratch_col[lp0 + x] = -1;
+            scratch_off[lp0 + x] = lp0 + n;
+        }
+        for (long long bb = ((long long)lp0 + 255) / 256 + tid; bb * 256 < (long long)lp0 + n; bb += 1024)
+            block_info[bb] = make_int2(i, (int)(bb * 256 - lp0));
+        if (tid == 0) row_tc[i] = tiles;
+        __syncthreads();
+    }
+}
+
 // row-local scratch -> reference layout (_C_tileColIdx, spgemm.cu:379; pair offsets :484)
 // One block per tile row: the row knows where its tiles go (c_rowptr[i]) and where its scratch lives (its first
 // pair), so the copy is two coalesced streams and needs no search.  (One WAVE per row was as fast on a whole matrix,
@@ -1416,7 +1577,7 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     const int *__restrict__ c_tile_nnz_ptr, long long nnz_c, const uint8_t *__restrict__ c_rowcolidx, VT *__restrict__ c_vals,
     const int *__restrict__ a_nnz_ptr, const VT *__restrict__ a_vals, const uint32_t *__restrict__ a_rec,
     const int *__restrict__ b_nnz_ptr, const VT *__restrict__ b_vals_t, const uint32_t *__restrict__ b_rec_t,
-    const int *__restrict__ chunk_tile, const uint32_t *__restrict__ c_mask)
+    const int *__restrict__ chunk_tile, const uint32_t *__restrict__ c_mask, const int epw)
 {
     __shared__ __attribute__((aligned(16))) uint4 s_rp[DECODE ? 4 * 64 : 1];        // [wave][tile]: prefix counts of the tile's 16 rows, one byte each
     __shared__ unsigned s_mw[DECODE ? 4 * 8 * 64 : 1];                                // [wave][word q][tile]: (row 2q) << 16 | row 2q+1
@@ -1429,10 +1590,13 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     // shuffle search with no memory traffic.
     const int lane = threadIdx.x & 63;
     const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long long eb = wave * S3_EPW;
+    // epw = entries per wave, a multiple of S3_CHUNK: 256 where C tiles are sparse (a wave's entries then span ~64 tiles, one
+    // load of the per-tile registers); more where they are dense (25 entries per tile on the round-3 webbase-1M stand-in: the
+    // 64 tiles a wave loads cover 1 600 entries, and at 256 entries per wave six waves would each load them)
+    const long long eb = wave * epw;
     if (eb >= nnz_c) return;
-    const int e_lo = (int)eb, e_hi = (int)(eb + S3_EPW < nnz_c ? eb + S3_EPW : nnz_c);
-    const long long lo = chunk_tile[wave];   // the tile entry e_lo lies in (noted by s2_entries_kernel)
+    const int e_lo = (int)eb, e_hi = (int)(eb + epw < nnz_c ? eb + epw : nnz_c);
+    const long long lo = chunk_tile[wave * (epw / S3_CHUNK)];   // the tile entry e_lo lies in (noted by step 2)
     for (long long t0 = lo; t0 < ntc; t0 += 64) {
         const long long tl = t0 + lane < ntc ? t0 + lane : ntc - 1;
         const int my_off = (t0 + lane < ntc) ? c_tile_nnz_ptr[tl] : 0x7FFFFFFF;   // value offset of tile t0+lane
@@ -2106,6 +2270,11 @@ extern "C" pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const p
     p->opt_export_rows = env_is("PEM_EXPORT", "rows");
     p->opt_s1_serial = getenv("PEM_S1_SERIAL") != nullptr;
     p->opt_decode = !env_is("PEM_S3_DECODE", "0");
+    p->opt_xl_global = env_is("PEM_S1_XL_GLOBAL", "1");
+    {
+        const char *e = getenv("PEM_S3_EPW");
+        p->opt_epw = e ? atoi(e) : 0;
+    }
     *out = p;
     return PEM_OK;
 }
@@ -2148,6 +2317,8 @@ static int *plan_option_slot(pem_cplan *p, pem_option which)
     case PEM_OPT_EXPORT_ROWS: return &p->opt_export_rows;
     case PEM_OPT_S1_SERIAL: return &p->opt_s1_serial;
     case PEM_OPT_S3_DECODE: return &p->opt_decode;
+    case PEM_OPT_S1_XL_GLOBAL: return &p->opt_xl_global;
+    case PEM_OPT_S3_EPW: return &p->opt_epw;
     default: return nullptr;
     }
 }
@@ -2160,7 +2331,7 @@ extern "C" pem_status pem_cplan_set_option(pem_cplan *plan, pem_option which, in
         set_error("pem_cplan_set_option: unknown option %d or value %lld out of range", (int)which, (long long)value);
         return PEM_E_INVALID;
     }
-    const int v = which == PEM_OPT_S1_XLCAP ? (int)value : (value != 0);
+    const int v = (which == PEM_OPT_S1_XLCAP || which == PEM_OPT_S3_EPW) ? (int)value : (value != 0);
     if (*slot == v) return PEM_OK;
     *slot = v;
     // a repeat pass re-uses the sizes (and possibly the captured graph) of the previous one: whatever changes the kernels
@@ -2249,7 +2420,7 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_LAUNCH(ctx, s1_xl_expand_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_keys.as<long long>(), A->tile_rowptr.as<int>(),
                    A->tile_occ.as<uint32_t>(), p->a_lo, nA, p->tr_lo, p->lprod_off.as<int>(), (const int *)nullptr, B->tile_rowptr.as<int>(),
                    B->tile_colidx.as<int>(), B->tile_occ.as<uint32_t>(), prune, bits_tc, p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(),
-                   p->prod_a.as<int>(), p->prod_b.as<int>());
+                   p->prod_a.as<int>(), p->prod_b.as<int>(), 0);
         uint64_t *keys = nullptr;
         PEM_TRY(radix_sort_u64_u32(ctx, p->sk0.as<uint64_t>(), p->sk1.as<uint64_t>(), p->sv0.as<uint32_t>(), p->sv1.as<uint32_t>(), n,
                                    bits_tc + bits_row, &keys, &p->sorted_perm));
@@ -2423,8 +2594,9 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     int64_t P = 0, Pall = 0;
     int counts[4];
     size_t n_xl;
-    int nrows_xl = 0;
+    int nrows_xl = 0, max_xl = 0;
     if (p->warm_pass) {
+        max_xl = p->w_max_xl;
         P = p->w_P;
         Pall = p->w_Pall;
         for (int b = 0; b < 4; ++b) counts[b] = p->w_counts[b];
@@ -2440,6 +2612,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         for (int b = 0; b < 4; ++b) counts[b] = p->w_counts[b] = hb[b];
         n_xl = (size_t)hb[5];
         nrows_xl = p->w_nrows_xl = hb[4];
+        max_xl = p->w_max_xl = hb[6];
         p->w_nxl = (int64_t)n_xl;
         p->w_P = P;
         p->w_Pall = Pall;
@@ -2462,11 +2635,12 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->scratch_col.reserve(sizeof(int) * (n + 4)));
         PEM_TRY(p->scratch_off.reserve(sizeof(int) * (n + 4)));
         PEM_TRY(p->block_info.reserve(sizeof(int2) * (n / 256 + 4)));
-        if (k32)
-            launch_rowsorts<uint32_t>(ctx, p, counts, mt, cap3, prune, false);
-        else
-            launch_rowsorts<uint64_t>(ctx, p, counts, mt, cap3, prune, rank2);
-        if (n_xl > 0) {   // oversized rows: global expand + stable radix sort on (row, tile col)
+        // Oversized rows.  Up to S1_XLL_MAX live products each they are sorted where they lie, one workgroup per row: three
+        // launches with no shared scratch, so the chain runs on a stream of its own BESIDE the row bins (it is a third of the
+        // bins' time on webbase-1M; behind them it was a quarter of the whole pass).  Larger ones go through the global sort,
+        // after the bins (it uses the context's scan and sort scratch).
+        const bool xl_local = n_xl > 0 && !p->opt_xl_global && max_xl <= S1_XLL_MAX;
+        if (n_xl > 0) {
             PEM_TRY(p->prod_a.reserve(sizeof(int) * n_xl));
             PEM_TRY(p->prod_b.reserve(sizeof(int) * n_xl));
             PEM_TRY(p->sk0.reserve(sizeof(uint64_t) * n_xl));
@@ -2475,12 +2649,35 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
             PEM_TRY(p->sv1.reserve(sizeof(uint32_t) * n_xl));
             PEM_TRY(p->xl_rowstart.reserve(sizeof(int) * ((size_t)mt + 4)));
             PEM_TRY(p->xl_lrel.reserve(sizeof(int) * ((size_t)nA + 4)));
+        }
+        auto xl_expand = [&](int local) {
             PEM_LAUNCH(ctx, s1_xl_rel_kernel, (unsigned)(nrows_xl > 0 ? nrows_xl : 1), 256, p->row_list.as<int>() + (size_t)4 * mt, nrows_xl,
                        A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->lprod_off.as<int>(), p->xl_lrel.as<int>());
             PEM_LAUNCH(ctx, s1_xl_expand_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_keys.as<long long>(), A->tile_rowptr.as<int>(),
                        A->tile_occ.as<uint32_t>(), p->a_lo, nA, p->tr_lo, p->xl_lrel.as<int>(), p->xl_base.as<int>(), B->tile_rowptr.as<int>(),
                        B->tile_colidx.as<int>(), B->tile_occ.as<uint32_t>(), prune, bits_tc, p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(),
-                       p->prod_a.as<int>(), p->prod_b.as<int>());
+                       p->prod_a.as<int>(), p->prod_b.as<int>(), local);
+        };
+        if (xl_local) {
+            hipStream_t main_stream = ctx->stream;
+            (void)hipEventRecord(ctx->ev_fork, main_stream);
+            (void)hipStreamWaitEvent(ctx->aux[3], ctx->ev_fork, 0);
+            ctx->stream = ctx->aux[3];
+            xl_expand(1);
+            PEM_LAUNCH(ctx, s1_xl_rowsort_kernel, (unsigned)(nrows_xl > 0 ? nrows_xl : 1), 1024, p->row_list.as<int>() + (size_t)4 * mt, nrows_xl,
+                       p->xl_base.as<int>(), p->row_lbase.as<int>(), p->sk0.as<uint64_t>(), p->sk1.as<uint64_t>(), bits_tc, p->prod_a.as<int>(),
+                       p->prod_b.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(),
+                       p->block_info.as<int2>(), p->c_tile_rowptr.as<int>());
+            (void)hipEventRecord(ctx->ev_join[3], ctx->aux[3]);
+            ctx->stream = main_stream;
+        }
+        if (k32)
+            launch_rowsorts<uint32_t>(ctx, p, counts, mt, cap3, prune, false);
+        else
+            launch_rowsorts<uint64_t>(ctx, p, counts, mt, cap3, prune, rank2);
+        if (xl_local) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join[3], 0);
+        if (n_xl > 0 && !xl_local) {   // global expand + stable radix sort on (row, tile col)
+            xl_expand(0);
             uint64_t *keys = nullptr;
             uint32_t *perm = nullptr;
             PEM_TRY(radix_sort_u64_u32(ctx, p->sk0.as<uint64_t>(), p->sk1.as<uint64_t>(), p->sv0.as<uint32_t>(), p->sv1.as<uint32_t>(), n_xl,
@@ -2694,23 +2891,23 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
     const bool wide = p->wide;   // step 2's choice: the entry-per-lane kernel needs the chunk index the fused path wrote
     const bool f32 = A->value_bytes == 4;
 #define PEM_S3_WIDE(VT, DEEP, NAME)                                                                                                            \
-    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, DEEP>), grid_for(((size_t)p->nnz_c + S3_EPW - 1) / S3_EPW * 64, 256), 256,     \
+    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, DEEP>), grid_for(((size_t)p->nnz_c + s3_epw - 1) / s3_epw * 64, 256), 256,     \
                      p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),       \
                      (long long)p->nnz_c, p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),       \
                      A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                  \
-                     p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>())
+                     p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>(), (int)s3_epw)
 #define PEM_S3_DECODE(VT, NAME)                                                                                                                \
-    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, false, false, true>), grid_for(((size_t)p->nnz_c + S3_EPW - 1) / S3_EPW * 64, 256), 256, \
+    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, false, false, true>), grid_for(((size_t)p->nnz_c + s3_epw - 1) / s3_epw * 64, 256), 256, \
                      p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),       \
                      (long long)p->nnz_c, (const uint8_t *)nullptr, p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),           \
                      A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                  \
-                     p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>())
+                     p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>(), (int)s3_epw)
 #define PEM_S3_WIDE3(VT, NAME)                                                                                                                 \
-    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, true, true>), grid_for(((size_t)p->nnz_c + S3_EPW - 1) / S3_EPW * 64, 256), 256, \
+    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, true, true>), grid_for(((size_t)p->nnz_c + s3_epw - 1) / s3_epw * 64, 256), 256, \
                      p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),       \
                      (long long)p->nnz_c, p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),       \
                      A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                  \
-                     p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>())
+                     p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>(), (int)s3_epw)
 #define PEM_S3_LAUNCH(VT)                                                                                                                      \
     do {                                                                                                                                       \
         if (wide && deep && p->opt_band) {                                                                                                     \
@@ -2732,6 +2929,8 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
                        B->tile_nnz_ptr.as<int>(), B->vals.as<VT>(), B->masks.as<uint16_t>(), B->rowptr.as<uint8_t>(), B->masks_t.as<uint16_t>()); \
     } while (0)
     const bool deep = p->npairs >= 2 * p->ntiles_c;   // two or more pairs per C tile on average (see the kernel)
+    // entries per wave: 256, or 1024 where the C tiles hold 8+ entries on average (see the kernel); PEM_OPT_S3_EPW forces 256 * value
+    const size_t s3_epw = (size_t)S3_EPW * (size_t)(p->opt_epw > 0 ? p->opt_epw : (ntc > 0 && (size_t)p->nnz_c >= 8 * ntc && !deep) ? 4 : 1);
     if (ntc > 0 && f32)
         PEM_S3_LAUNCH(float);
     else if (ntc > 0)

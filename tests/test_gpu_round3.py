@@ -193,3 +193,33 @@ def test_step3_reads_rows_and_columns_off_the_masks(pkg, oracle, ctx, name, dtyp
     ctx.set_kernel_profiling(False)
     if not deep and info["ntiles_c"] > 0:      # the decode kernel really ran, and the entry kernel did not
         assert any("decode" in k for k in names) and "s2_entries_kernel" not in names, names
+
+
+@pytest.mark.parametrize("name", ["hub_row_4000", "blockrows_10000", "xl_mixed_AAt", "k64_bins", "powerlaw_600"])
+@pytest.mark.parametrize("prune", [1, 0])
+def test_oversized_rows_sorted_per_row_and_globally(pkg, oracle, ctx, name, prune):
+    """Tile rows beyond the LDS bins (here: forced by PEM_OPT_S1_XLCAP; on the webbase-1M stand-in its directory pages, whose
+    4 700 A tiles fit no LDS table) are sorted one workgroup per row in global memory (s1_xl_rowsort_kernel) by default, and by
+    the global (row, tile column) radix sort with PEM_OPT_S1_XL_GLOBAL.  Both must give the oracle's lists, cold and warm."""
+    gA, gB, oA, oB = _pair(pkg, oracle, ctx, CASES[name])
+    want, counts = expected(oracle.Plan(oA, oB), oA, oB, bool(prune))
+    for cap in (40, 300):
+        for glob in (0, 1):
+            plan = pkg.CPlan(ctx, gA, gB)
+            plan.set_option("prune", prune)
+            plan.set_option("s1_xlcap", cap)
+            plan.set_option("s1_xl_global", glob)
+            ctx.set_kernel_profiling(True)
+            ctx.reset_kernel_stats()
+            for _ in range(2):
+                plan.spgemm()
+                info = plan.info()
+                assert (info["ntiles_c"], info["npairs"], info["nnz_c"], info["npairs_all"]) == counts, (cap, glob)
+                for arr in C_NAMES:
+                    assert np.array_equal(plan.array(arr), want[arr]), f"{name} cap {cap} global {glob} prune {prune}: {arr} differs"
+            names = list(ctx.kernel_stats())
+            ctx.set_kernel_profiling(False)
+            if info["npairs"] > cap and any(k.startswith("s1_xl_expand") for k in names):
+                assert ("s1_xl_rowsort_kernel" in names) == (glob == 0), names
+                assert ("s1_xl_emit_kernel" in names) == (glob == 1), names
+            plan.close()
