@@ -82,9 +82,10 @@ def parse_args(argv=None):
     ap.add_argument("--grid", default=None, metavar="RxC",
                     help="N>1: 2-D partition (SURVEY 8(f)-4), R row blocks of A x C column blocks of B, R*C = --gpus; each rank "
                          "holds only its rows of A and its columns of B.  Default: 1-D row blocks, B replicated (the BASELINE configs)")
-    ap.add_argument("--chunks", type=int, default=0, metavar="K",
+    ap.add_argument("--chunks", type=int, default=-1, metavar="K",
                     help="N>1, 1-D: also time the pipelined form -- each rank's row block in K chunks, chunk c's CSR travelling "
-                         "to rank 0 while chunk c+1 computes (SURVEY 8(f)-4); reported as exchange.pipelined")
+                         "to rank 0 while chunk c+1 computes (SURVEY 8(f)-4); reported as exchange.pipelined.  Default -1: K chosen "
+                         "from C's size (~48 MB of CSR per chunk, 2..8); 0: off")
     ap.add_argument("--no-graph", action="store_true", help="time plain stream launches instead of hipGraph replay of the repeat passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-r2", action="store_true", help="skip the continuity leg: the round-2 stand-in of the headline workload timed beside it")
@@ -359,13 +360,20 @@ def main(argv=None):
             exchange_error = f"{type(e).__name__}: {e}"
             gather = False
     pipelined = None
-    if gather and grid is None and args.chunks > 0 and not aat:
-        cb = pkg.split_tile_rows(ctx, A, B, world * args.chunks)
-        crb = mg.ChunkedRowBlock(pkg, ctx, A, B, cb, rank, args.chunks, torch_dt, dst=0)
+    nchunks = args.chunks
+    if nchunks < 0 and world > 1:
+        # the overlapped gather is part of the default N>1 line: K from the bytes one rank sends (12 B per C entry)
+        tn = torch.tensor([plan.info()["nnz_c"]], dtype=torch.int64, device=dev)
+        if dist is not None:
+            dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+        nchunks = int(max(2, min(8, -(-int(tn.item()) * (vbytes + 4) // (48 << 20)))))
+    if gather and grid is None and nchunks > 0 and not aat:
+        cb = pkg.split_tile_rows(ctx, A, B, world * nchunks)
+        crb = mg.ChunkedRowBlock(pkg, ctx, A, B, cb, rank, nchunks, torch_dt, dst=0)
         crb.run_pass()                                            # sizes + staging buffers; plans warm up
         crb.run_pass()
         t_pipe = timed(lambda: bufs.__setitem__("pipe_out", crb.run_pass()), args.steps) * 1e3 / max(args.steps, 1)
-        pipelined = {"chunks": args.chunks, "ms_per_step": t_pipe,
+        pipelined = {"chunks": nchunks, "ms_per_step": t_pipe,
                      "what": "steps 1-3 of every chunk + device CSR export + gather to rank 0, chunk c in flight while chunk c+1 computes",
                      "sequential_ms_per_step": ms_per_step + exchange_ms,
                      "value_with_exchange": 2.0 * flop / (t_pipe * 1e-3) / 1e9}

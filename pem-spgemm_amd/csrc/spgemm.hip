@@ -2929,8 +2929,9 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
                        B->tile_nnz_ptr.as<int>(), B->vals.as<VT>(), B->masks.as<uint16_t>(), B->rowptr.as<uint8_t>(), B->masks_t.as<uint16_t>()); \
     } while (0)
     const bool deep = p->npairs >= 2 * p->ntiles_c;   // two or more pairs per C tile on average (see the kernel)
-    // entries per wave: 256, or 1024 where the C tiles hold 8+ entries on average (see the kernel); PEM_OPT_S3_EPW forces 256 * value
-    const size_t s3_epw = (size_t)S3_EPW * (size_t)(p->opt_epw > 0 ? p->opt_epw : (ntc > 0 && (size_t)p->nnz_c >= 8 * ntc && !deep) ? 4 : 1);
+    // entries per wave: 256, or 512 where the C tiles hold 8+ entries on average (see the kernel; 562 / 534 / 536 / 574 us at 256 / 512 /
+    // 1024 / 2048 on the round-3 webbase-1M stand-in); PEM_OPT_S3_EPW forces 256 * value
+    const size_t s3_epw = (size_t)S3_EPW * (size_t)(p->opt_epw > 0 ? p->opt_epw : (ntc > 0 && (size_t)p->nnz_c >= 8 * ntc && !deep) ? 2 : 1);
     if (ntc > 0 && f32)
         PEM_S3_LAUNCH(float);
     else if (ntc > 0)

@@ -166,6 +166,38 @@ def test_cage15_rank_slice_against_cpu_port(pkg, oracle, standins, ctx):
     assert np.array_equal(v, v0)
 
 
+def test_cage15_whole_matrix_in_eight_slices_against_cpu_port(pkg, oracle, standins, ctx):
+    """BASELINE configs[4], the whole of it: all eight row blocks of the full-size cage15 stand-in, one after the other on this
+    GPU, each compared with the OpenMP Gustavson port on the same rows -- entry counts, row-pointer and column-index sums
+    exactly, value sums to 1e-9 of the absolute sum (round 2 compared rank 0's block only; that block is still compared
+    array by array above).  Together the blocks are the whole C: the sizes must add up to the product's literature size
+    (~0.93 G entries, the stand-in is calibrated to within 5 %)."""
+    rows, cols, I, J, V = standins.make("cage15", 1.0)
+    A = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V)
+    bounds = pkg.split_tile_rows(ctx, A, A, 8)
+    ob = oracle.Csr(rows, cols, I, J, V)
+    total_nnz, total_flop = 0, pkg.flop_count(ctx, A, A)
+    for part in range(8):
+        lo, hi = int(bounds[part]), int(bounds[part + 1])
+        plan = pkg.CPlan(ctx, A, A, lo, hi)
+        plan.spgemm()
+        rp, ci, v = plan.export_csr()
+        info = plan.info()
+        plan.close()
+        r0, r1 = info["row_begin"], info["row_end"]
+        sel = (I >= r0) & (I < r1)
+        oa = oracle.Csr(r1 - r0, cols, I[sel] - r0, J[sel], V[sel])
+        rp0, ci0, v0 = oracle.csr_spgemm(oa, ob, oracle.max_threads()).arrays()
+        assert len(ci) == len(ci0) == info["nnz_c"], part
+        assert int(rp.astype(np.int64).sum()) == int(rp0.astype(np.int64).sum()), part
+        assert int(ci.astype(np.int64).sum()) == int(ci0.astype(np.int64).sum()), part
+        assert abs(float(v.sum()) - float(v0.sum())) <= 1e-9 * float(np.abs(v0).sum()), part
+        assert np.array_equal(rp, rp0), part                   # (cheap: one int per row)
+        total_nnz += len(ci)
+        del rp, ci, v, rp0, ci0, v0, oa, sel
+    assert abs(total_nnz / 0.93e9 - 1.0) < 0.05 and abs(total_flop / 2.08e9 - 1.0) < 0.05, (total_nnz, total_flop)
+
+
 def test_cli_gpus_path_gathers_through_rccl_library(pkg, oracle, standins, tmp_path):
     """`pemspgemm --gpus N` (one context per device, slices gathered by libpemmgpu.so over RCCL): with the one GPU of this
     box the communicator has one rank, but conversion per rank, the row split, the threaded passes, the device CSR export
