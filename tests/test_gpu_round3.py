@@ -223,3 +223,29 @@ def test_oversized_rows_sorted_per_row_and_globally(pkg, oracle, ctx, name, prun
                 assert ("s1_xl_rowsort_kernel" in names) == (glob == 0), names
                 assert ("s1_xl_emit_kernel" in names) == (glob == 1), names
             plan.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_dense_and_sparse_tiles_of_one_product(pkg, oracle, standins, ctx, dtype):
+    """The round-3 webbase-1M stand-in (here 3 % of it) mixes nearly full C tiles (hosts whose pages all link to the index
+    pages and back: prefixes up to 240, entry 255 in the mask decoding) with tiles of two or three entries.  CSR against the
+    serial Gustavson oracle bit for bit (fp64), identical with the decoding switched off, and with 256 / 1024 entries per wave."""
+    rows, cols, I, J, V = standins.make("webbase-1M", 0.03)
+    A = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V, dtype=dtype)
+    plan = pkg.CPlan(ctx, A, A)
+    plan.spgemm()
+    plan.spgemm()
+    got = plan.export_csr()
+    for opt, val in (("s3_decode", 0), ("s3_epw", 1), ("s3_epw", 4)):
+        plan.set_option("s3_decode", 1)
+        plan.set_option("s3_epw", 0)
+        plan.set_option(opt, val)
+        plan.spgemm()
+        for a, b in zip(got, plan.export_csr()):
+            assert np.array_equal(a, b), (opt, val)
+    if dtype == np.float64:
+        oa = oracle.Csr(rows, cols, I, J, V)
+        for a, b in zip(got, oracle.csr_spgemm(oa, oa).arrays()):
+            assert np.array_equal(a, b)
+    counts = np.bincount(np.repeat(np.arange(len(got[0]) - 1) // 16, np.diff(got[0])).astype(np.int64) * ((cols + 15) // 16) + got[1] // 16)
+    assert (counts >= 64).sum() > 100 and ((counts > 0) & (counts < 8)).sum() > 100      # the input really has both kinds
