@@ -173,6 +173,9 @@ typedef enum {
                                        lie; 1: all of them through one global radix sort on (row, tile column) (rows above 2^18 live
                                        products always)                                                                              */
     PEM_OPT_S3_EPW = 11,            /* step 3: C entries per wave / 256 (0, default: 1, or 4 where C tiles hold 8+ entries on average) */
+    PEM_OPT_S3_IDX64 = 12,          /* test hook: the mask-decoding step 3 addresses with 64-bit indices whatever the sizes (default: 32-bit
+                                       byte offsets on scalar bases while every array of the product is < 4 GiB)                     */
+    PEM_OPT_S3_MARK = 13,           /* 1 (default; pruned plans): entry -> tile lookup by LDS marks + one ballot; 0: six-step shuffle search */
     PEM_OPT_S3_DECODE = 9           /* 1 (default): on plans with < 2 pairs per C tile step 3 reads (row, column) off the C masks and
                                        Ctiles_rowColIdx is materialised on demand; 0: step 2 writes it on every pass               */
 } pem_option;

@@ -290,6 +290,8 @@ struct pem_cplan {
     int opt_band = 1;                                  // 0: many-pair tiles stay in the entry-per-lane kernel
     int opt_step1_esc = 0, opt_wide = 1, opt_warm = 1, opt_export_rows = 0, opt_s1_serial = 0;
     int opt_xl_global = 0;                             // oversized rows: the global (row, tile column) radix sort instead of one workgroup per row
+    int opt_idx64 = 0;                                 // test hook: 64-bit addressing in the shallow step 3 whatever the sizes
+    int opt_mark = 1;                                  // shallow, pruned plans: entry -> tile by marks + ballot instead of the shuffle search
     int opt_epw = 0;                                   // step 3: entries per wave / 256 (0: chosen from the C tiles' density)
     int opt_decode = 1;                                // shallow plans: step 3 reads (row, column) off the C masks, no Ctiles_rowColIdx on the pass
     int64_t ntiles_c = 0, npairs = 0, nnz_c = 0;

@@ -1566,12 +1566,27 @@ constexpr int S3_BAND_MIN = 8;       // C tiles with at least this many pairs go
 constexpr int S3_BAND_CH = 16;       // pairs whose records one wave stages in LDS at a time (multiple of 4, at most 64)
 constexpr int S3_BAND_RS = S3_BAND_CH + 4;   // row stride of the staged records (words): 16-byte aligned, rows on different banks
 constexpr int S3_BAND_H = 1;         // meeting pairs a lane sums per trip of the gather loop
+// 32-bit addressing (IDX32): base pointer in scalar registers + a 32-bit byte offset -- one shift per gather where 64-bit
+// indexing takes a sign extension and a 64-bit shift-add (49 + 20 of the kernel's 341 static vector-ALU instructions; the step
+// is bound by instruction issue on dense-tile inputs).  Valid only while every array is smaller than 4 GiB: the host checks.
+template <bool IDX32, typename T> __device__ __forceinline__ T s3_ld(const T *__restrict__ base, const long long idx)
+{
+    if constexpr (IDX32)
+        return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)((unsigned)idx * (unsigned)sizeof(T)));
+    else
+        return base[idx];
+}
+
 // DECODE: the entries' (row, column) are read off the C tile's mask instead of Ctiles_rowColIdx.  The 64 tiles a wave holds
 // one per lane put their mask words and their intra-tile row pointers (the sixteen bytes of Ctiles_rowPtr, spgemm.cu:579-580)
 // into a wave-private patch of LDS; entry n of a tile then finds its row by a 4-step search over those bytes (they never
 // decrease) and its column as the k-th set bit of the row's mask: ~35 VALU and two LDS reads per entry in place of a global
 // byte load, and step 2 no longer has to write (or re-read its masks for) the bytes at all.
-template <typename VT, bool DEEP, bool BAND = false, bool DECODE = false>
+// MARK (pruned plans only: every C tile has an entry, so tile offsets strictly increase): the entry -> tile lookup of a trip
+// without the six-step shuffle search -- the tiles that start inside the trip's 64 entries mark their first entry in a
+// 64-word LDS strip, one ballot turns the strip into a bit mask, and an entry's tile is (tiles started before the trip) +
+// (marks at or below its lane) - 1.
+template <typename VT, bool DEEP, bool BAND = false, bool DECODE = false, bool IDX32 = false, bool MARK = false>
 __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b, long long ntc,
     const int *__restrict__ c_tile_nnz_ptr, long long nnz_c, const uint8_t *__restrict__ c_rowcolidx, VT *__restrict__ c_vals,
@@ -1581,6 +1596,9 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
 {
     __shared__ __attribute__((aligned(16))) uint4 s_rp[DECODE ? 4 * 64 : 1];        // [wave][tile]: prefix counts of the tile's 16 rows, one byte each
     __shared__ unsigned s_mw[DECODE ? 4 * 8 * 64 : 1];                                // [wave][word q][tile]: (row 2q) << 16 | row 2q+1
+    static_assert(!(DEEP && (IDX32 || MARK)), "the shallow variant's options");
+    __shared__ int s_head[MARK ? 4 * 64 : 1];                                         // [wave][entry of the trip]: a tile starts here
+    int *const my_head = s_head + (MARK ? (threadIdx.x >> 6) * 64 : 0);
     uint4 *const my_rp = s_rp + (DECODE ? (threadIdx.x >> 6) * 64 : 0);
     unsigned *const my_mw = s_mw + (DECODE ? (threadIdx.x >> 6) * 8 * 64 : 0);
     // Work is dealt by ENTRIES, S3_EPW per wave, so hub rows (tiles with many entries and pairs) cannot pile
@@ -1599,17 +1617,17 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     const long long lo = chunk_tile[wave * (epw / S3_CHUNK)];   // the tile entry e_lo lies in (noted by step 2)
     for (long long t0 = lo; t0 < ntc; t0 += 64) {
         const long long tl = t0 + lane < ntc ? t0 + lane : ntc - 1;
-        const int my_off = (t0 + lane < ntc) ? c_tile_nnz_ptr[tl] : 0x7FFFFFFF;   // value offset of tile t0+lane
-        const int my_p0 = pairs_offset[tl], my_p1 = pairs_offset[tl + 1];
+        const int my_off = (t0 + lane < ntc) ? s3_ld<IDX32>(c_tile_nnz_ptr, tl) : 0x7FFFFFFF;   // value offset of tile t0+lane
+        const int my_p0 = s3_ld<IDX32>(pairs_offset, tl), my_p1 = s3_ld<IDX32>(pairs_offset, tl + 1);
         // the tile's FIRST pair and its operands' value offsets, one gather set per tile: 92 % of webbase-1M's C tiles have
         // one pair, so most entries get their whole pair record by shuffle instead of four loads of their own (the step is
         // bound by the number of vector-memory instructions, section 4 of DESIGN.md)
-        const int my_a0 = pairs_a[my_p0], my_b0 = pairs_b[my_p0];
-        const int my_av0 = a_nnz_ptr[my_a0], my_bv0 = b_nnz_ptr[my_b0];
+        const int my_a0 = s3_ld<IDX32>(pairs_a, my_p0), my_b0 = s3_ld<IDX32>(pairs_b, my_p0);
+        const int my_av0 = s3_ld<IDX32>(a_nnz_ptr, my_a0), my_bv0 = s3_ld<IDX32>(b_nnz_ptr, my_b0);
         // ... and the second pair of the tiles that have one (7 %): their entries' second trip then costs 4 instructions, not 8
         const bool two = my_p1 - my_p0 >= 2;
-        const int my_a1 = two ? pairs_a[my_p0 + 1] : 0, my_b1 = two ? pairs_b[my_p0 + 1] : 0;
-        const int my_av1 = two ? a_nnz_ptr[my_a1] : 0, my_bv1 = two ? b_nnz_ptr[my_b1] : 0;
+        const int my_a1 = two ? s3_ld<IDX32>(pairs_a, (long long)my_p0 + 1) : 0, my_b1 = two ? s3_ld<IDX32>(pairs_b, (long long)my_p0 + 1) : 0;
+        const int my_av1 = two ? s3_ld<IDX32>(a_nnz_ptr, my_a1) : 0, my_bv1 = two ? s3_ld<IDX32>(b_nnz_ptr, my_b1) : 0;
         const long long tend = t0 + 64 < ntc ? t0 + 64 : ntc;
         const int chunk_end = c_tile_nnz_ptr[tend];
         const int first = __shfl(my_off, 0, 64);
@@ -1642,10 +1660,27 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
         const bool valid = e < e_end;
         // tile of entry e: largest lane index ti with off[ti] <= e (offsets are non-decreasing)
         int ti = 0;
+        if constexpr (MARK) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the previous trip's marks have been read
+            __builtin_amdgcn_wave_barrier();
+            my_head[lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned st = (unsigned)(my_off - ebase);             // (a tile that started before the trip, or a lane past the last tile: out of range)
+            if (st < 64u) my_head[st] = 1;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const unsigned long long marks = __ballot(my_head[lane] != 0);
+            const int before = __popcll(__ballot(my_off < ebase));      // tiles that started before the trip (>= 1 unless one starts at its first entry)
+            ti = before - 1 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(marks >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)marks, 0u)) +
+                 (int)((marks >> lane) & 1ull);
+        } else {
 #pragma unroll
-        for (int step = 32; step > 0; step >>= 1) {
-            int probe = __shfl(my_off, ti + step, 64);
-            if (probe <= e) ti += step;
+            for (int step = 32; step > 0; step >>= 1) {
+                int probe = __shfl(my_off, ti + step, 64);
+                if (probe <= e) ti += step;
+            }
         }
         const int p0 = __shfl(my_p0, ti, 64), p1 = __shfl(my_p1, ti, 64);
         const int a0 = __shfl(my_a0, ti, 64), b0 = __shfl(my_b0, ti, 64), av0 = __shfl(my_av0, ti, 64), bv0 = __shfl(my_bv0, ti, 64);
@@ -1692,30 +1727,28 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
         VT acc = VT(0);
         int p = p0;
         if (!DEEP) {   // first pair: everything but the two records and the values is already here
-            const unsigned aw = a_rec[16 * (size_t)a0 + r], bw = b_rec_t[16 * (size_t)b0 + c];
+            const unsigned aw = s3_ld<IDX32>(a_rec, 16ll * a0 + r), bw = s3_ld<IDX32>(b_rec_t, 16ll * b0 + c);
             const unsigned am = aw & 0xFFFFu, bm = bw & 0xFFFFu;
             unsigned m = am & bm;
-            const VT *av = a_vals + av0 + (aw >> 16);
-            const VT *bv = b_vals_t + bv0 + (bw >> 16);
+            const int ao = av0 + (int)(aw >> 16), bo = bv0 + (int)(bw >> 16);
             while (m) {
                 const int kk = __builtin_ctz(m);
                 m &= m - 1;
                 const unsigned below = (1u << kk) - 1u;
-                acc = pem_fma(av[__popc(am & below)], bv[__popc(bm & below)], acc);
+                acc = pem_fma(s3_ld<IDX32>(a_vals, (long long)ao + __popc(am & below)), s3_ld<IDX32>(b_vals_t, (long long)bo + __popc(bm & below)), acc);
             }
             ++p;
             {
                 if (p < p1) {             // second pair
-                    const unsigned aw1 = a_rec[16 * (size_t)a1 + r], bw1 = b_rec_t[16 * (size_t)b1 + c];
+                    const unsigned aw1 = s3_ld<IDX32>(a_rec, 16ll * a1 + r), bw1 = s3_ld<IDX32>(b_rec_t, 16ll * b1 + c);
                     const unsigned am1 = aw1 & 0xFFFFu, bm1 = bw1 & 0xFFFFu;
                     unsigned m1 = am1 & bm1;
-                    const VT *av = a_vals + av1 + (aw1 >> 16);
-                    const VT *bv = b_vals_t + bv1 + (bw1 >> 16);
+                    const int ao1 = av1 + (int)(aw1 >> 16), bo1 = bv1 + (int)(bw1 >> 16);
                     while (m1) {
                         const int kk = __builtin_ctz(m1);
                         m1 &= m1 - 1;
                         const unsigned below = (1u << kk) - 1u;
-                        acc = pem_fma(av[__popc(am1 & below)], bv[__popc(bm1 & below)], acc);
+                        acc = pem_fma(s3_ld<IDX32>(a_vals, (long long)ao1 + __popc(am1 & below)), s3_ld<IDX32>(b_vals_t, (long long)bo1 + __popc(bm1 & below)), acc);
                     }
                     ++p;
                 }
@@ -1787,25 +1820,27 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
             }
         }
         for (; p < p1; ++p) {
-            const int a = pairs_a[p], b = pairs_b[p];
-            const unsigned aw = a_rec[16 * (size_t)a + r];
+            const int a = s3_ld<IDX32>(pairs_a, p), b = s3_ld<IDX32>(pairs_b, p);
+            const unsigned aw = s3_ld<IDX32>(a_rec, 16ll * a + r);
             const unsigned am = aw & 0xFFFFu;
             // B is read by column here: its transposed record (rows holding column c | entries in the columns before)
             // and its column-major values give every operand with one record gather + one value gather per product
-            const unsigned bw = b_rec_t[16 * (size_t)b + c];
+            const unsigned bw = s3_ld<IDX32>(b_rec_t, 16ll * b + c);
             const unsigned bm = bw & 0xFFFFu;
             unsigned m = am & bm;
             if (!m) continue;
-            const VT *av = a_vals + a_nnz_ptr[a] + (aw >> 16);
-            const VT *bv = b_vals_t + b_nnz_ptr[b] + (bw >> 16);
+            const int ao = s3_ld<IDX32>(a_nnz_ptr, a) + (int)(aw >> 16), bo = s3_ld<IDX32>(b_nnz_ptr, b) + (int)(bw >> 16);
             while (m) {
                 const int kk = __builtin_ctz(m);
                 m &= m - 1;
                 const unsigned below = (1u << kk) - 1u;
-                acc = pem_fma(av[__popc(am & below)], bv[__popc(bm & below)], acc);
+                acc = pem_fma(s3_ld<IDX32>(a_vals, (long long)ao + __popc(am & below)), s3_ld<IDX32>(b_vals_t, (long long)bo + __popc(bm & below)), acc);
             }
         }
-        c_vals[e] = acc;
+        if constexpr (IDX32)
+            *reinterpret_cast<VT *>(reinterpret_cast<char *>(c_vals) + (size_t)((unsigned)e * (unsigned)sizeof(VT))) = acc;
+        else
+            c_vals[e] = acc;
     }
         if (chunk_end >= e_hi) break;
     }
@@ -2271,6 +2306,8 @@ extern "C" pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const p
     p->opt_s1_serial = getenv("PEM_S1_SERIAL") != nullptr;
     p->opt_decode = !env_is("PEM_S3_DECODE", "0");
     p->opt_xl_global = env_is("PEM_S1_XL_GLOBAL", "1");
+    p->opt_idx64 = env_is("PEM_S3_IDX64", "1");
+    p->opt_mark = !env_is("PEM_S3_MARK", "0");
     {
         const char *e = getenv("PEM_S3_EPW");
         p->opt_epw = e ? atoi(e) : 0;
@@ -2319,6 +2356,8 @@ static int *plan_option_slot(pem_cplan *p, pem_option which)
     case PEM_OPT_S3_DECODE: return &p->opt_decode;
     case PEM_OPT_S1_XL_GLOBAL: return &p->opt_xl_global;
     case PEM_OPT_S3_EPW: return &p->opt_epw;
+    case PEM_OPT_S3_IDX64: return &p->opt_idx64;
+    case PEM_OPT_S3_MARK: return &p->opt_mark;
     default: return nullptr;
     }
 }
@@ -2896,8 +2935,8 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
                      (long long)p->nnz_c, p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),       \
                      A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                  \
                      p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>(), (int)s3_epw)
-#define PEM_S3_DECODE(VT, NAME)                                                                                                                \
-    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, false, false, true>), grid_for(((size_t)p->nnz_c + s3_epw - 1) / s3_epw * 64, 256), 256, \
+#define PEM_S3_DECODE(VT, I32, MK, NAME)                                                                                                       \
+    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, false, false, true, I32, MK>), grid_for(((size_t)p->nnz_c + s3_epw - 1) / s3_epw * 64, 256), 256, \
                      p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),       \
                      (long long)p->nnz_c, (const uint8_t *)nullptr, p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),           \
                      A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                  \
@@ -2918,8 +2957,14 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
                              A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>());         \
         } else if (wide && deep)                                                                                                               \
             PEM_S3_WIDE(VT, true, "s3_accumulate_wide_kernel<" #VT ",deep>");                                                                  \
+        else if (wide && p->s3_decode && idx32 && mark)                                                                                        \
+            PEM_S3_DECODE(VT, true, true, "s3_accumulate_wide_kernel<" #VT ",decode,idx32,mark>");                                             \
+        else if (wide && p->s3_decode && idx32)                                                                                                \
+            PEM_S3_DECODE(VT, true, false, "s3_accumulate_wide_kernel<" #VT ",decode,idx32>");                                                 \
+        else if (wide && p->s3_decode && mark)                                                                                                 \
+            PEM_S3_DECODE(VT, false, true, "s3_accumulate_wide_kernel<" #VT ",decode,mark>");                                                  \
         else if (wide && p->s3_decode)                                                                                                         \
-            PEM_S3_DECODE(VT, "s3_accumulate_wide_kernel<" #VT ",decode>");                                                                    \
+            PEM_S3_DECODE(VT, false, false, "s3_accumulate_wide_kernel<" #VT ",decode>");                                                      \
         else if (wide)                                                                                                                         \
             PEM_S3_WIDE(VT, false, "s3_accumulate_wide_kernel<" #VT ">");                                                                      \
         else                                                                                                                                   \
@@ -2932,6 +2977,13 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
     // entries per wave: 256, or 512 where the C tiles hold 8+ entries on average (see the kernel; 562 / 534 / 536 / 574 us at 256 / 512 /
     // 1024 / 2048 on the round-3 webbase-1M stand-in); PEM_OPT_S3_EPW forces 256 * value
     const size_t s3_epw = (size_t)S3_EPW * (size_t)(p->opt_epw > 0 ? p->opt_epw : (ntc > 0 && (size_t)p->nnz_c >= 8 * ntc && !deep) ? 2 : 1);
+    // 32-bit byte offsets on scalar bases where every array the shallow kernel touches is smaller than 4 GiB; the marked
+    // entry -> tile lookup where no C tile is empty (pruned lists)
+    const size_t gib4 = (size_t)1 << 32, vb = (size_t)A->value_bytes;
+    const bool idx32 = !p->opt_idx64 && 32 * (ntc + 1) < gib4 && 4 * ((size_t)p->npairs + 4) < gib4 && 64 * ((size_t)A->ntiles + 1) < gib4 &&
+                       64 * ((size_t)B->ntiles + 1) < gib4 && vb * ((size_t)A->nnz + 1) < gib4 && vb * ((size_t)B->nnz + 1) < gib4 &&
+                       vb * ((size_t)p->nnz_c + 1) < gib4;
+    const bool mark = p->opt_mark && p->opt_prune;
     if (ntc > 0 && f32)
         PEM_S3_LAUNCH(float);
     else if (ntc > 0)

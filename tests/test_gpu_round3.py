@@ -178,6 +178,16 @@ def test_step3_reads_rows_and_columns_off_the_masks(pkg, oracle, ctx, name, dtyp
     assert np.array_equal(v_dec, v_ref), "values differ between the mask-decoding step 3 and the byte-reading one"
     for a, b in zip(csr_dec, plan.export_csr()):
         assert np.array_equal(a, b)
+    # the decoding kernel's addressing (32-bit offsets / 64-bit indices) and entry -> tile lookup (marks / shuffle search)
+    plan.set_option("s3_decode", 1)
+    for idx64, mark in ((1, 1), (0, 0), (1, 0)):
+        plan.set_option("s3_idx64", idx64)
+        plan.set_option("s3_mark", mark)
+        plan.spgemm()
+        plan.spgemm()
+        assert np.array_equal(plan.array("c_vals"), v_ref), f"idx64={idx64} mark={mark}: values differ"
+    plan.set_option("s3_idx64", 0)
+    plan.set_option("s3_mark", 1)
     if dtype == np.float64:
         oA = oracle.Tiled(rows, cols, I, J, V, False)
         oB = oracle.Tiled(rows, cols, I, J, V, True) if tr else oA
@@ -236,9 +246,9 @@ def test_dense_and_sparse_tiles_of_one_product(pkg, oracle, standins, ctx, dtype
     plan.spgemm()
     plan.spgemm()
     got = plan.export_csr()
-    for opt, val in (("s3_decode", 0), ("s3_epw", 1), ("s3_epw", 4)):
-        plan.set_option("s3_decode", 1)
-        plan.set_option("s3_epw", 0)
+    for opt, val in (("s3_decode", 0), ("s3_epw", 1), ("s3_epw", 4), ("s3_idx64", 1), ("s3_mark", 0), ("prune", 0)):
+        for k, v in (("s3_decode", 1), ("s3_epw", 0), ("s3_idx64", 0), ("s3_mark", 1), ("prune", 1)):
+            plan.set_option(k, v)
         plan.set_option(opt, val)
         plan.spgemm()
         for a, b in zip(got, plan.export_csr()):
