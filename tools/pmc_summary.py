@@ -10,18 +10,33 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+
+
+def canon(name):
+    """rocprofv3's kernel name -> the name the library's own per-kernel timing (PEM_LAUNCH_NAMED) and bench.py use"""
+    base = name.split("(")[0].replace("pem::", "").replace("void ", "").strip()
+    if base.startswith("s3_accumulate_wide_kernel<"):
+        args = [a.strip() for a in base[base.index("<") + 1:base.rindex(">")].split(",")]
+        flags = args[1:] + ["false"] * (6 - len(args))          # <VT, DEEP, BAND, DECODE, IDX32, MARK>
+        tags = [t for t, f in zip(("deep", "band", "decode", "idx32", "mark"), flags) if f == "true"]
+        return "s3_accumulate_wide_kernel<" + ",".join([args[0]] + tags) + ">"
+    if base.startswith("s1_rowsort_kernel<"):
+        args = [a.strip() for a in base[base.index("<") + 1:base.rindex(">")].split(",")]
+        return "s1_rowsort_kernel<" + args[1] + (",rank" if len(args) > 5 and args[5] == "true" else "") + ">"
+    return base
+
 per = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> [values]
 dur = defaultdict(list)
 for path in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recursive=True):
     with open(path) as f:
         for row in csv.DictReader(f):
             name = row.get("Kernel_Name", "")
-            short = name.split("(")[0].replace("pem::", "").replace("void ", "").replace(", false, false>", ">").replace(", true, false>", ",deep>").replace(", true, true>", ",deep,band>")
+            short = canon(name)
             per[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for path in glob.glob(os.path.join(out, "sq", "**", "*kernel_trace.csv"), recursive=True):
     with open(path) as f:
         for row in csv.DictReader(f):
-            short = row["Kernel_Name"].split("(")[0].replace("pem::", "").replace("void ", "").replace(", false, false>", ">").replace(", true, false>", ",deep>").replace(", true, true>", ",deep,band>")
+            short = canon(row["Kernel_Name"])
             dur[short].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
 cols = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_LDS",
         "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]
