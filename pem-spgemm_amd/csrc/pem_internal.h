@@ -284,6 +284,7 @@ struct pem_cplan {
     const pem_tiled *A = nullptr, *B = nullptr;
     int tr_lo = 0, tr_hi = 0;
     int a_lo = 0, a_hi = 0;            // A tile id range of the slice
+    int max_row_tiles = 0;             // A tiles in the slice's longest tile row
     int state = 0;                     // 0 created, 1 step1 done, 2 step2 done, 3 step3 done
     // pem_option values (include/pem_spgemm.h); defaults come from the environment when the plan is created
     int opt_prune = 1, opt_key64 = 0, opt_xlcap = 0;

@@ -120,11 +120,23 @@ __global__ void __launch_bounds__(256) s1_xl_expand_kernel(const long long *__re
                                                            const int *__restrict__ b_tile_rowptr, const int *__restrict__ b_tile_colidx,
                                                            const uint32_t *__restrict__ b_occ, int prune, int bits_tc,
                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, int *__restrict__ prod_a,
-                                                           int *__restrict__ prod_b, int local_keys)
+                                                           int *__restrict__ prod_b, int local_keys, const int *__restrict__ xl_rows)
 {
-    const int arel = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    // xl_rows != nullptr: a two-dimensional grid over the oversized rows only -- blockIdx.y picks the row, blockIdx.x sixteen of
+    // its A tiles (the grid covers the plan's longest tile row; blocks past a row's end leave at once) -- instead of one pass
+    // over every A tile of the slice, of which all but the few oversized rows' exit after two loads
+    int arel;
+    bool in;
+    if (xl_rows) {
+        const int xi = xl_rows[blockIdx.y];
+        const int r0 = a_tile_rowptr[tr_lo + xi] - a_lo, r1 = a_tile_rowptr[tr_lo + xi + 1] - a_lo;
+        arel = r0 + (int)blockIdx.x * 16 + (int)(threadIdx.x >> 4);
+        in = arel < r1;
+    } else {
+        arel = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+        in = arel < nA;
+    }
     const int l = threadIdx.x & 15, grp = (threadIdx.x & 63) >> 4;
-    const bool in = arel < nA;
     int a = 0, i = 0, k = 0, x0 = -1, b0 = 0, len = 0;
     unsigned acol = 0xFFFFu;
     if (in) {
@@ -330,11 +342,14 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
     }
 }
 
-// oversized rows (global path): live-product offsets of the row's A tiles relative to the row, one block per row
-__global__ void __launch_bounds__(256) s1_xl_rel_kernel(const int *__restrict__ xl_rows, int nrows_xl, const int *__restrict__ a_tile_rowptr, int tr_lo,
-                                                        int a_lo, const int *__restrict__ lcnt, int *__restrict__ lrel)
+// oversized rows: live-product offsets of the row's A tiles relative to the row, one 1024-thread block per row (a directory
+// row of webbase-1M has 4 700 A tiles: five trips; with 256 threads it took nineteen, 16 us on a chain that is the critical
+// path of a rank's share of an 8-way split)
+__global__ void __launch_bounds__(1024) s1_xl_rel_kernel(const int *__restrict__ xl_rows, int nrows_xl, const int *__restrict__ a_tile_rowptr, int tr_lo,
+                                                         int a_lo, const int *__restrict__ lcnt, int *__restrict__ lrel)
 {
-    __shared__ int wsum[4];
+    constexpr int WAVES = 16;
+    __shared__ int wsum[WAVES];
     __shared__ int carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int li = blockIdx.x; li < nrows_xl; li += gridDim.x) {
@@ -342,7 +357,7 @@ __global__ void __launch_bounds__(256) s1_xl_rel_kernel(const int *__restrict__ 
         const int a0 = a_tile_rowptr[tr_lo + i] - a_lo, a1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
         if (threadIdx.x == 0) carry_s = 0;
         __syncthreads();
-        for (int x0 = a0; x0 < a1; x0 += 256) {
+        for (int x0 = a0; x0 < a1; x0 += 1024) {
             const int x = x0 + threadIdx.x;
             const int c = x < a1 ? lcnt[x] : 0;
             int inc = c;
@@ -355,7 +370,7 @@ __global__ void __launch_bounds__(256) s1_xl_rel_kernel(const int *__restrict__ 
             __syncthreads();
             int woff = carry_s, tot = 0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < WAVES; ++w) {
                 if (w < wave) woff += wsum[w];
                 tot += wsum[w];
             }
@@ -2284,6 +2299,8 @@ extern "C" pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const p
     p->tr_hi = tr_hi;
     p->a_lo = A->h_tile_rowptr[(size_t)tr_lo];
     p->a_hi = A->h_tile_rowptr[(size_t)tr_hi];
+    for (int i = tr_lo; i < tr_hi; ++i)      // the longest tile row of the slice (grid of the oversized rows' expansion)
+        p->max_row_tiles = std::max(p->max_row_tiles, A->h_tile_rowptr[(size_t)i + 1] - A->h_tile_rowptr[(size_t)i]);
     // Every switch is a property of the PLAN, latched here (pem_cplan_set_option changes it later): a C ABI whose behaviour
     // followed the process environment at call time is not a boundary a maintainer can bind.  The environment variables only
     // give the DEFAULTS a new plan starts from (test hooks: PEM_S1_FORCE_KEY64 / PEM_S1_XLCAP push small inputs through the
@@ -2459,7 +2476,7 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_LAUNCH(ctx, s1_xl_expand_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_keys.as<long long>(), A->tile_rowptr.as<int>(),
                    A->tile_occ.as<uint32_t>(), p->a_lo, nA, p->tr_lo, p->lprod_off.as<int>(), (const int *)nullptr, B->tile_rowptr.as<int>(),
                    B->tile_colidx.as<int>(), B->tile_occ.as<uint32_t>(), prune, bits_tc, p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(),
-                   p->prod_a.as<int>(), p->prod_b.as<int>(), 0);
+                   p->prod_a.as<int>(), p->prod_b.as<int>(), 0, (const int *)nullptr);
         uint64_t *keys = nullptr;
         PEM_TRY(radix_sort_u64_u32(ctx, p->sk0.as<uint64_t>(), p->sk1.as<uint64_t>(), p->sv0.as<uint32_t>(), p->sv1.as<uint32_t>(), n,
                                    bits_tc + bits_row, &keys, &p->sorted_perm));
@@ -2690,12 +2707,14 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
             PEM_TRY(p->xl_lrel.reserve(sizeof(int) * ((size_t)nA + 4)));
         }
         auto xl_expand = [&](int local) {
-            PEM_LAUNCH(ctx, s1_xl_rel_kernel, (unsigned)(nrows_xl > 0 ? nrows_xl : 1), 256, p->row_list.as<int>() + (size_t)4 * mt, nrows_xl,
+            PEM_LAUNCH(ctx, s1_xl_rel_kernel, (unsigned)(nrows_xl > 0 ? nrows_xl : 1), 1024, p->row_list.as<int>() + (size_t)4 * mt, nrows_xl,
                        A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->lprod_off.as<int>(), p->xl_lrel.as<int>());
-            PEM_LAUNCH(ctx, s1_xl_expand_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_keys.as<long long>(), A->tile_rowptr.as<int>(),
+            // (the grid: the oversized rows x sixteen A tiles per block up to the plan's longest tile row)
+            const dim3 xgrid((unsigned)((p->max_row_tiles + 15) / 16 > 0 ? (p->max_row_tiles + 15) / 16 : 1), (unsigned)(nrows_xl > 0 ? nrows_xl : 1));
+            PEM_LAUNCH(ctx, s1_xl_expand_kernel, xgrid, 256, A->tile_keys.as<long long>(), A->tile_rowptr.as<int>(),
                        A->tile_occ.as<uint32_t>(), p->a_lo, nA, p->tr_lo, p->xl_lrel.as<int>(), p->xl_base.as<int>(), B->tile_rowptr.as<int>(),
                        B->tile_colidx.as<int>(), B->tile_occ.as<uint32_t>(), prune, bits_tc, p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(),
-                       p->prod_a.as<int>(), p->prod_b.as<int>(), local);
+                       p->prod_a.as<int>(), p->prod_b.as<int>(), local, p->row_list.as<int>() + (size_t)4 * mt);
         };
         if (xl_local) {
             hipStream_t main_stream = ctx->stream;
