@@ -176,6 +176,7 @@ typedef enum {
     PEM_OPT_S3_IDX64 = 12,          /* test hook: the mask-decoding step 3 addresses with 64-bit indices whatever the sizes (default: 32-bit
                                        byte offsets on scalar bases while every array of the product is < 4 GiB)                     */
     PEM_OPT_S3_MARK = 13,           /* 1 (default; pruned plans): entry -> tile lookup by LDS marks + one ballot; 0: six-step shuffle search */
+    PEM_OPT_S3_XCD = 14,            /* 1 (default): step 3's entry-per-lane kernels give XCD x the x-th contiguous eighth of C; 0: round-robin */
     PEM_OPT_S3_DECODE = 9           /* 1 (default): on plans with < 2 pairs per C tile step 3 reads (row, column) off the C masks and
                                        Ctiles_rowColIdx is materialised on demand; 0: step 2 writes it on every pass               */
 } pem_option;

@@ -293,6 +293,7 @@ struct pem_cplan {
     int opt_xl_global = 0;                             // oversized rows: the global (row, tile column) radix sort instead of one workgroup per row
     int opt_idx64 = 0;                                 // test hook: 64-bit addressing in the shallow step 3 whatever the sizes
     int opt_mark = 1;                                  // shallow, pruned plans: entry -> tile by marks + ballot instead of the shuffle search
+    int opt_s3_xcd = 1;                                // step 3 (entry-per-lane kernels): XCD x takes the x-th contiguous eighth of C
     int opt_epw = 0;                                   // step 3: entries per wave / 256 (0: chosen from the C tiles' density)
     int opt_decode = 1;                                // shallow plans: step 3 reads (row, column) off the C masks, no Ctiles_rowColIdx on the pass
     int64_t ntiles_c = 0, npairs = 0, nnz_c = 0;

@@ -1607,7 +1607,7 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     const int *__restrict__ c_tile_nnz_ptr, long long nnz_c, const uint8_t *__restrict__ c_rowcolidx, VT *__restrict__ c_vals,
     const int *__restrict__ a_nnz_ptr, const VT *__restrict__ a_vals, const uint32_t *__restrict__ a_rec,
     const int *__restrict__ b_nnz_ptr, const VT *__restrict__ b_vals_t, const uint32_t *__restrict__ b_rec_t,
-    const int *__restrict__ chunk_tile, const uint32_t *__restrict__ c_mask, const int epw)
+    const int *__restrict__ chunk_tile, const uint32_t *__restrict__ c_mask, const int epw, const int xcd)
 {
     __shared__ __attribute__((aligned(16))) uint4 s_rp[DECODE ? 4 * 64 : 1];        // [wave][tile]: prefix counts of the tile's 16 rows, one byte each
     __shared__ unsigned s_mw[DECODE ? 4 * 8 * 64 : 1];                                // [wave][word q][tile]: (row 2q) << 16 | row 2q+1
@@ -1622,7 +1622,10 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     // their value offsets and pair ranges sit one per lane in registers, and the entry -> tile lookup is a 6-step
     // shuffle search with no memory traffic.
     const int lane = threadIdx.x & 63;
-    const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    // xcd != 0 (the grid is then a multiple of eight blocks): workgroups go to the eight XCDs round-robin, so XCD x takes the
+    // x-th contiguous eighth of C -- consecutive entry ranges, which share their A and B tiles, then meet in ONE L2
+    const unsigned vblock = xcd ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const long long wave = ((long long)vblock * blockDim.x + threadIdx.x) >> 6;
     // epw = entries per wave, a multiple of S3_CHUNK: 256 where C tiles are sparse (a wave's entries then span ~64 tiles, one
     // load of the per-tile registers); more where they are dense (25 entries per tile on the round-3 webbase-1M stand-in: the
     // 64 tiles a wave loads cover 1 600 entries, and at 256 entries per wave six waves would each load them)
@@ -2323,6 +2326,7 @@ extern "C" pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const p
     p->opt_s1_serial = getenv("PEM_S1_SERIAL") != nullptr;
     p->opt_decode = !env_is("PEM_S3_DECODE", "0");
     p->opt_xl_global = env_is("PEM_S1_XL_GLOBAL", "1");
+    p->opt_s3_xcd = !env_is("PEM_S3_XCD", "0");
     p->opt_idx64 = env_is("PEM_S3_IDX64", "1");
     p->opt_mark = !env_is("PEM_S3_MARK", "0");
     {
@@ -2373,6 +2377,7 @@ static int *plan_option_slot(pem_cplan *p, pem_option which)
     case PEM_OPT_S3_DECODE: return &p->opt_decode;
     case PEM_OPT_S1_XL_GLOBAL: return &p->opt_xl_global;
     case PEM_OPT_S3_EPW: return &p->opt_epw;
+    case PEM_OPT_S3_XCD: return &p->opt_s3_xcd;
     case PEM_OPT_S3_IDX64: return &p->opt_idx64;
     case PEM_OPT_S3_MARK: return &p->opt_mark;
     default: return nullptr;
@@ -2949,23 +2954,23 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
     const bool wide = p->wide;   // step 2's choice: the entry-per-lane kernel needs the chunk index the fused path wrote
     const bool f32 = A->value_bytes == 4;
 #define PEM_S3_WIDE(VT, DEEP, NAME)                                                                                                            \
-    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, DEEP>), grid_for(((size_t)p->nnz_c + s3_epw - 1) / s3_epw * 64, 256), 256,     \
+    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, DEEP>), (grid_for(((size_t)p->nnz_c + s3_epw - 1) / s3_epw * 64, 256) + 7u) & ~7u, 256,     \
                      p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),       \
                      (long long)p->nnz_c, p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),       \
                      A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                  \
-                     p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>(), (int)s3_epw)
+                     p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>(), (int)s3_epw, s3_xcd)
 #define PEM_S3_DECODE(VT, I32, MK, NAME)                                                                                                       \
-    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, false, false, true, I32, MK>), grid_for(((size_t)p->nnz_c + s3_epw - 1) / s3_epw * 64, 256), 256, \
+    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, false, false, true, I32, MK>), (grid_for(((size_t)p->nnz_c + s3_epw - 1) / s3_epw * 64, 256) + 7u) & ~7u, 256, \
                      p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),       \
                      (long long)p->nnz_c, (const uint8_t *)nullptr, p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),           \
                      A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                  \
-                     p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>(), (int)s3_epw)
+                     p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>(), (int)s3_epw, s3_xcd)
 #define PEM_S3_WIDE3(VT, NAME)                                                                                                                 \
-    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, true, true>), grid_for(((size_t)p->nnz_c + s3_epw - 1) / s3_epw * 64, 256), 256, \
+    PEM_LAUNCH_NAMED(ctx, NAME, (s3_accumulate_wide_kernel<VT, true, true>), (grid_for(((size_t)p->nnz_c + s3_epw - 1) / s3_epw * 64, 256) + 7u) & ~7u, 256, \
                      p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)ntc, p->c_tile_nnz_ptr.as<int>(),       \
                      (long long)p->nnz_c, p->c_rowcolidx.as<uint8_t>(), p->c_vals.as<VT>(), A->tile_nnz_ptr.as<int>(), A->vals.as<VT>(),       \
                      A->tile_rec.as<uint32_t>(), B->tile_nnz_ptr.as<int>(), B->vals_t.as<VT>(), B->tile_rec_t.as<uint32_t>(),                  \
-                     p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>(), (int)s3_epw)
+                     p->s3_chunk_tile.as<int>(), p->c_mask.as<uint32_t>(), (int)s3_epw, s3_xcd)
 #define PEM_S3_LAUNCH(VT)                                                                                                                      \
     do {                                                                                                                                       \
         if (wide && deep && p->opt_band) {                                                                                                     \
@@ -3003,6 +3008,7 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
                        64 * ((size_t)B->ntiles + 1) < gib4 && vb * ((size_t)A->nnz + 1) < gib4 && vb * ((size_t)B->nnz + 1) < gib4 &&
                        vb * ((size_t)p->nnz_c + 1) < gib4;
     const bool mark = p->opt_mark && p->opt_prune;
+    const int s3_xcd = p->opt_s3_xcd;
     if (ntc > 0 && f32)
         PEM_S3_LAUNCH(float);
     else if (ntc > 0)

@@ -246,8 +246,8 @@ def test_dense_and_sparse_tiles_of_one_product(pkg, oracle, standins, ctx, dtype
     plan.spgemm()
     plan.spgemm()
     got = plan.export_csr()
-    for opt, val in (("s3_decode", 0), ("s3_epw", 1), ("s3_epw", 4), ("s3_idx64", 1), ("s3_mark", 0), ("prune", 0)):
-        for k, v in (("s3_decode", 1), ("s3_epw", 0), ("s3_idx64", 0), ("s3_mark", 1), ("prune", 1)):
+    for opt, val in (("s3_decode", 0), ("s3_epw", 1), ("s3_epw", 4), ("s3_idx64", 1), ("s3_mark", 0), ("prune", 0), ("s3_xcd", 0)):
+        for k, v in (("s3_decode", 1), ("s3_epw", 0), ("s3_idx64", 0), ("s3_mark", 1), ("prune", 1), ("s3_xcd", 1)):
             plan.set_option(k, v)
         plan.set_option(opt, val)
         plan.spgemm()
