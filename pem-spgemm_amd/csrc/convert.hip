@@ -283,6 +283,16 @@ extern "C" pem_status pem_ctx_create_on_stream(int device, void *stream, pem_ctx
         ctx->own_stream = true;
     }
     PEM_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalars), sizeof(int64_t) * 64, hipHostMallocDefault));
+    {
+        static_assert(NUM_FLAGS <= 16, "the flag mirror takes the last eight 64-bit slots of h_scalars");
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, ctx->h_scalars, 0) == hipSuccess && dp) {
+            ctx->h_flags = reinterpret_cast<volatile int *>(ctx->h_scalars + 56);
+            ctx->h_flags_dev = reinterpret_cast<int *>(reinterpret_cast<int64_t *>(dp) + 56);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     PEM_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_scalars), sizeof(int64_t) * 64));
     PEM_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_flags), sizeof(int) * NUM_FLAGS));
     PEM_HIP(hipMemsetAsync(ctx->d_scalars, 0, sizeof(int64_t) * 64, ctx->stream));

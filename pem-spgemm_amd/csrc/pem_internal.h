@@ -181,6 +181,8 @@ struct pem_ctx {
     // pinned host page for scalar read-backs (replaces the reference's racy pageable
     // cudaMemcpyAsync of _C_nnz / d_pairs_count / C_nnz)
     int64_t *h_scalars = nullptr;      // 64 slots
+    volatile int *h_flags = nullptr;   // the status flags of a repeat pass, written by the pass's checking thread (host view; slots 56..)
+    int *h_flags_dev = nullptr;        // ... the device's address of the same words (null: not mappable, copy instead)
     int64_t *d_scalars = nullptr;      // 64 slots on the device
     int *d_flags = nullptr;            // NUM_FLAGS ints
     // shared temporaries (grow-only, reused by every call on this context)
@@ -321,6 +323,7 @@ struct pem_cplan {
     // row-local step 1
     pem::DevBuf row_list, bin_count, xl_base, xl_rowstart, scratch_col, scratch_off;
     bool pairs_ready = false;          // step 1 already wrote pairs_a / pairs_b
+    bool flags_mirrored = false;       // ... and left the pass's status flags in ctx->h_flags
     bool verify_folded = false;        // this pass's size check ran inside s2_entries_kernel
     bool group_nnz_cleared = false;    // step 1's reset already zeroed group_nnz for this pass
     bool wide = true;                  // step 2 ran the fused kernel (step 3 then runs entry-per-lane); false: 16-lanes-per-tile baseline

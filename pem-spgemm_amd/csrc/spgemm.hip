@@ -1434,6 +1434,7 @@ struct WarmCheck {
     int on;
     long long P, Pall, TC, nnz, nxl;
     int c0, c1, c2, c3;
+    int *host_flags;     // where set: the pass's status flags are left in host memory by the checking thread (no copy node after the pass)
 };
 __device__ __forceinline__ void warm_check(const WarmCheck &w, const long long *__restrict__ d_scalars, const int *__restrict__ bin_count,
                                            int *__restrict__ flags)
@@ -1441,6 +1442,10 @@ __device__ __forceinline__ void warm_check(const WarmCheck &w, const long long *
     if (d_scalars[0] != w.P || d_scalars[1] != w.TC || d_scalars[2] != w.nnz || d_scalars[3] != w.Pall || bin_count[0] != w.c0 ||
         bin_count[1] != w.c1 || bin_count[2] != w.c2 || bin_count[3] != w.c3 || bin_count[5] != w.nxl)
         flags[FLAG_CAPACITY] = 1;
+    if (w.host_flags) {
+        // the caller guarantees that nothing after this thread sets a flag in this pass (s2_offsets_kernel + step 3: none do)
+        for (int i = 0; i < NUM_FLAGS; ++i) w.host_flags[i] = flags[i];
+    }
 }
 
 __global__ void __launch_bounds__(S2_GROUP) s2_entries_kernel(const uint32_t *__restrict__ c_mask, long long ntc, const int *__restrict__ group_base,
@@ -2828,6 +2833,7 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
     const bool fused = p->pairs_ready && p->opt_wide;
     p->wide = fused;
     p->verify_folded = false;
+    p->flags_mirrored = false;
     p->s3_decode = false;
     p->c_rowcolidx_valid = false;
     int64_t nnzc = 0;
@@ -2876,8 +2882,13 @@ static pem_status step2_impl(pem_ctx *ctx, pem_cplan *p)
                                              {&p->c_vals, (size_t)A->value_bytes * ((size_t)nnzc + 1)}}));
             PEM_TRY(p->s3_chunk_tile.reserve(sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)));
             WarmCheck wc = {};
-            if (p->warm_pass) wc = WarmCheck{1, p->w_P, p->w_Pall, p->w_TC, p->w_nnz, p->w_nxl, p->w_counts[0], p->w_counts[1], p->w_counts[2], p->w_counts[3]};
+            if (p->warm_pass) wc = WarmCheck{1, p->w_P, p->w_Pall, p->w_TC, p->w_nnz, p->w_nxl, p->w_counts[0], p->w_counts[1], p->w_counts[2], p->w_counts[3], nullptr};
             p->verify_folded = p->warm_pass;
+            // s2_offsets_kernel's checking thread is the last writer of a flag in the pass: it leaves all of them in host memory
+            if (p->warm_pass && decode && ctx->h_flags_dev) {
+                wc.host_flags = ctx->h_flags_dev;
+                p->flags_mirrored = true;
+            }
             if (decode) {
                 PEM_LAUNCH(ctx, s2_offsets_kernel, grid_for(((ntc + S2_GROUP) / S2_GROUP) * 64, 256), 256, p->c_tile_cnt.as<uint16_t>(), (long long)ntc,
                            group_nnz, p->c_tile_nnz_ptr.as<int>(), p->s3_chunk_tile.as<int>(), ctx->d_flags, wc,
@@ -3075,7 +3086,7 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
     auto launch_verify = [&]() {
         if (plan->verify_folded) return;   // step 2's last kernel has already compared the sizes
         const WarmCheck wc = {1, plan->w_P, plan->w_Pall, plan->w_TC, plan->w_nnz, plan->w_nxl, plan->w_counts[0], plan->w_counts[1],
-                              plan->w_counts[2], plan->w_counts[3]};
+                              plan->w_counts[2], plan->w_counts[3], nullptr};
         PEM_LAUNCH(ctx, warm_verify_kernel, 1, 1, reinterpret_cast<const long long *>(ctx->d_scalars), plan->bin_count.as<int>(), wc, ctx->d_flags);
     };
     // Graph replay (pem_set_graph_replay): a repeat pass has fixed grids, sizes and buffer addresses, so its ~28 launches,
@@ -3115,7 +3126,12 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
         if (plan->graph_exec) {
             PEM_HIP(hipGraphLaunch(plan->graph_exec, ctx->stream));
             int hf[NUM_FLAGS];
-            PEM_TRY(read_flags(ctx, hf));
+            if (plan->flags_mirrored) {   // the flags are already in host memory when the graph ends: no copy behind it
+                PEM_HIP(hipStreamSynchronize(ctx->stream));
+                for (int i = 0; i < NUM_FLAGS; ++i) hf[i] = ctx->h_flags[i];
+            } else {
+                PEM_TRY(read_flags(ctx, hf));
+            }
             PEM_TRY(check_internal(hf));
             if (hf[FLAG_CAPACITY]) {   // sizes differ from the captured ones (cannot happen while A and B are immutable)
                 (void)hipGraphExecDestroy(plan->graph_exec);
@@ -3134,7 +3150,12 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
             // repeat pass: the host never waited for P / T_C / C_nnz; check on the device that they are what it assumed
             launch_verify();
             int hf[NUM_FLAGS];
-            PEM_TRY(read_flags(ctx, hf));   // the pass's one synchronisation
+            if (plan->flags_mirrored) {
+                PEM_HIP(hipStreamSynchronize(ctx->stream));   // the pass's one synchronisation
+                for (int i = 0; i < NUM_FLAGS; ++i) hf[i] = ctx->h_flags[i];
+            } else {
+                PEM_TRY(read_flags(ctx, hf));
+            }
             PEM_TRY(check_internal(hf));
             if (hf[FLAG_CAPACITY]) {        // cannot happen while A and B are immutable; recover by a full pass
                 plan->warm = false;
