@@ -259,3 +259,51 @@ def test_dense_and_sparse_tiles_of_one_product(pkg, oracle, standins, ctx, dtype
             assert np.array_equal(a, b)
     counts = np.bincount(np.repeat(np.arange(len(got[0]) - 1) // 16, np.diff(got[0])).astype(np.int64) * ((cols + 15) // 16) + got[1] // 16)
     assert (counts >= 64).sum() > 100 and ((counts > 0) & (counts < 8)).sum() > 100      # the input really has both kinds
+
+
+def _special_values_matrix(n=700, seed=5):
+    """Explicit zeros of both signs, subnormals, huge and tiny magnitudes, infinities and NaNs among ordinary values; a dense
+    block so that several products meet in one entry, and sparse rows around it."""
+    rng = np.random.default_rng(seed)
+    dense = [(r, c) for r in range(40, 72) for c in range(40, 72) if rng.random() < 0.7]
+    sparse = {(int(r), int(c)) for r, c in zip(rng.integers(0, n, 6000), rng.integers(0, n, 6000))}
+    coords = sorted(set(dense) | sparse)
+    I = np.array([p[0] for p in coords], dtype=np.int32)
+    J = np.array([p[1] for p in coords], dtype=np.int32)
+    V = rng.uniform(-1.0, 1.0, len(I))
+    V[V == 0] = 0.5
+    special = np.array([0.0, -0.0, 5e-324, -2.5e-310, 1e-200, -1e-200, 1e200, -1e200, 1.7e308, np.inf, -np.inf, np.nan])
+    pick = rng.random(len(I)) < 0.08
+    V[pick] = rng.choice(special, int(pick.sum()))
+    return n, n, I, J, V
+
+
+def _same_bits_or_both_nan(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    nan = np.isnan(a)
+    u = np.uint64 if a.dtype == np.float64 else np.uint32
+    return a.shape == b.shape and np.array_equal(nan, np.isnan(b)) and np.array_equal(a[~nan].view(u), b[~nan].view(u))
+
+
+def test_special_values_follow_the_fma_chain(pkg, oracle, ctx):
+    """Stored zeros (+0, -0), subnormals, 1e-200 .. 1.7e308, +-inf and NaN: C's structure is the structural product whatever
+    the values (a stored zero still makes an entry), and every value is the oracle's chain -- the sign of a zero sum, the
+    underflow to a subnormal, the overflow to inf included.  NaNs must sit where the oracle's sit (the payload of a NaN an
+    instruction makes up is the hardware's)."""
+    rows, cols, I, J, V = _special_values_matrix()
+    A = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V)
+    oa = oracle.Csr(rows, cols, I, J, V)
+    want = oracle.csr_spgemm(oa, oa).arrays()
+    assert np.isnan(want[2]).sum() > 10 and np.isinf(want[2]).sum() > 10 and (want[2] == 0).sum() > 10   # the input does what it says
+    for opts in ({}, {"s3_decode": 0}, {"wide": 0}, {"prune": 0}, {"s3_epw": 1}):
+        plan = pkg.CPlan(ctx, A, A)
+        for k, v in opts.items():
+            plan.set_option(k, v)
+        plan.spgemm()
+        plan.spgemm()                                   # (the repeat pass: graph-free warm plan)
+        got = plan.export_csr()
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), opts
+        assert _same_bits_or_both_nan(got[2], want[2]), opts
+        plan.close()
+    op = oracle.Plan(oracle.Tiled(rows, cols, I, J, V, False), oracle.Tiled(rows, cols, I, J, V, False))
+    assert _same_bits_or_both_nan(op.export_csr()[2], want[2])      # ... and the tiled oracle agrees with the serial one

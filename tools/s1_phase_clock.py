@@ -1,6 +1,6 @@
 """Diagnostic: phase clocks of the step-1 row-sort bins (needs a library built with `make EXTRA=-DPEM_S1_DEBUG`)."""
 import ctypes, importlib, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.environ.get("PEM_PKG_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # PEM_PKG_ROOT: a copy built with -DPEM_S1_DEBUG
 import numpy as np
 pkg = importlib.import_module("pem-spgemm_amd")
 standins = importlib.import_module("pem-spgemm_amd.standins")
