@@ -91,6 +91,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-r2", action="store_true", help="skip the continuity leg: the round-2 stand-in of the headline workload timed beside it")
     ap.add_argument("--no-gather", action="store_true", help="N>1: leave the C slices on their ranks")
+    ap.add_argument("--no-tune-split", action="store_true", help="N>1, A^2 row blocks: keep the first cut (balanced tile-level products) "
+                                                                 "instead of re-cutting it from measured per-rank times")
     ap.add_argument("--shared-input", default=None, metavar="DIR", help=argparse.SUPPRESS)   # set by the self-launcher
     return ap.parse_args(argv)
 
@@ -233,6 +235,7 @@ def main(argv=None):
         torch.cuda.synchronize()
         return t, len(a)
 
+    split_tuning = None
     if grid is None:
         (dI, dJ, dV), nnz = upload()
         if aat:
@@ -251,6 +254,21 @@ def main(argv=None):
         else:
             A = B = pkg.Tiled.from_coo_device(ctx, rows, cols, nnz, dI.data_ptr(), dJ.data_ptr(), dV.data_ptr(), False, dtype=np_dt)
             bounds = pkg.split_tile_rows(ctx, A, B, world)
+            if world > 1 and not args.no_tune_split:
+                # setup, untimed: re-cut the row blocks from measured per-rank pass times (multigpu.tune_row_bounds); any failure
+                # keeps the first cut
+                try:
+                    first = [int(x) for x in bounds]
+                    bounds, hist = mg.tune_row_bounds(pkg, ctx, A, B, bounds, rank, world, dev, graph=not args.no_graph)
+                    ctx.set_graph_replay(False)
+                    split_tuning = {"first_cut": first, "cut": [int(x) for x in bounds],
+                                    "rounds": [{"max_ms": float(t.max()), "min_ms": float(t.min()), "mean_ms": float(t.mean())} for _, t in hist],
+                                    "what": "row blocks re-cut from measured per-rank pass times before anything is timed "
+                                            "(first cut: tile-level product counts, pem_split_tile_rows)"}
+                except Exception as e:                          # noqa: BLE001
+                    ctx.set_graph_replay(False)
+                    split_tuning = {"error": f"{type(e).__name__}: {e}"}
+                    bounds = pkg.split_tile_rows(ctx, A, B, world)
         del dI, dJ, dV
         lo, hi = mg.slice_bounds(bounds, rank)
         flop = pkg.flop_count(ctx, A, B)
@@ -487,6 +505,7 @@ def main(argv=None):
             "conversion": state["conversion"],
             "export": state["export"],
             "standin_r2": state["standin_r2"],
+            "split_tuning": split_tuning,
             "memory": ctx.memory_stats(),
             "kernels": kern,
             "gen_s": t_gen,

@@ -250,6 +250,9 @@ pem_status pem_c_export_coo_f32(pem_ctx *ctx, const pem_cplan *plan, int64_t *nn
 /* bounds[0..nparts] tile-row boundaries of A, balanced on the per-tile-row intermediate
  * product count (the quantity of spgemm_nsparse_kernel.h:135-151 at tile level). */
 pem_status pem_split_tile_rows(pem_ctx *ctx, const pem_tiled *A, const pem_tiled *B, int nparts, int32_t *bounds);
+/* weights[0 .. A's tile rows): the per-tile-row weights pem_split_tile_rows balances (tile-level products + tiles + 1), for callers
+ * that cut their own row blocks -- e.g. re-cut them from measured per-rank times (multigpu.tune_row_bounds). */
+pem_status pem_tile_row_weights(pem_ctx *ctx, const pem_tiled *A, const pem_tiled *B, double *weights);
 
 /* ---- timings (spgemm.cu:1343-1354: the per-step spans of the benchmark CSV) -------------- */
 typedef struct {

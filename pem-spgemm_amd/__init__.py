@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "pem_tiled_from_coo", "pem_tiled_from_coo_device", "pem_tiled_from_csr", "pem_tiled_destroy", "pem_tiled_get_info",
     "pem_tiled_get_array", "pem_flop_count", "pem_cplan_create", "pem_cplan_destroy", "pem_spgemm_step1", "pem_spgemm_step2",
     "pem_spgemm_step3", "pem_spgemm", "pem_cplan_get_info", "pem_cplan_get_array", "pem_c_export_csr", "pem_c_export_csr_device",
-    "pem_c_export_coo", "pem_split_tile_rows", "pem_get_timings", "pem_set_kernel_profiling", "pem_reset_kernel_stats",
+    "pem_c_export_coo", "pem_split_tile_rows", "pem_tile_row_weights", "pem_get_timings", "pem_set_kernel_profiling", "pem_reset_kernel_stats",
     "pem_kernel_stats_count", "pem_kernel_stats_get", "pem_tiled_save", "pem_tiled_load",
     "pem_tiled_from_coo_f32", "pem_tiled_from_coo_device_f32", "pem_tiled_from_csr_f32", "pem_c_export_csr_f32",
     "pem_c_export_csr_device_f32", "pem_c_export_coo_f32", "pem_set_graph_replay",
@@ -282,6 +282,13 @@ def split_tile_rows(ctx, A, B, nparts):
     b = np.zeros(nparts + 1, dtype=np.int32)
     _check(lib().pem_split_tile_rows(ctx._h, A._h, B._h, int(nparts), _p(b, C.c_int32)))
     return b
+
+
+def tile_row_weights(ctx, A, B):
+    """the per-tile-row weights pem_split_tile_rows balances (float64, one per tile row of A)"""
+    w = np.zeros(A.tile_rows, dtype=np.float64)
+    _check(lib().pem_tile_row_weights(ctx._h, A._h, B._h, _p(w, C.c_double)))
+    return w
 
 
 class CPlan:

@@ -315,6 +315,8 @@ extern "C" pem_status pem_ctx_destroy(pem_ctx *ctx)
     if (!ctx) return PEM_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto ge : ctx->retired_graphs) (void)hipGraphExecDestroy(ge);
+    ctx->retired_graphs.clear();
     for (auto &s : ctx->pending) {
         (void)hipEventDestroy(s.e0);
         (void)hipEventDestroy(s.e1);

@@ -180,6 +180,7 @@ struct pem_ctx {
     bool own_stream = false;
     // pinned host page for scalar read-backs (replaces the reference's racy pageable
     // cudaMemcpyAsync of _C_nnz / d_pairs_count / C_nnz)
+    std::vector<hipGraphExec_t> retired_graphs;   // graph executables plans no longer use: destroyed with the context (see retire_graph)
     int64_t *h_scalars = nullptr;      // 64 slots
     volatile int *h_flags = nullptr;   // the status flags of a repeat pass, written by the pass's checking thread (host view; slots 56..)
     int *h_flags_dev = nullptr;        // ... the device's address of the same words (null: not mappable, copy instead)
@@ -332,6 +333,7 @@ struct pem_cplan {
     pem::DevBuf group_nnz;             // C entries per S2_GROUP tiles (s2_tiles_kernel -> scan -> s2_entries_kernel)
     // sizes of the last complete pass on this plan.  A and B are immutable, so a repeat pass has the same
     // sizes: it skips the three host read-backs and a device-side check compares them at the end instead.
+    pem_ctx *owner = nullptr;              // the context the plan was created on
     hipGraphExec_t graph_exec = nullptr;   // PEM_GRAPH=1: the captured warm pass
     unsigned long long graph_gen = 0;      // alloc_generation() at capture time
     bool graph_failed = false;             // capture or instantiation failed once: plain launches from then on

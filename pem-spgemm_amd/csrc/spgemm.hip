@@ -2301,6 +2301,7 @@ extern "C" pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const p
         return PEM_E_INVALID;
     }
     pem_cplan *p = new pem_cplan();
+    p->owner = ctx;
     p->A = A;
     p->B = B;
     p->tr_lo = tr_lo;
@@ -2342,13 +2343,28 @@ extern "C" pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const p
     return PEM_OK;
 }
 
+// A plan's instantiated graph is not destroyed when the plan lets go of it but when its CONTEXT goes: the HIP runtime of this image
+// (ROCm 7.x) keeps state across the graph executables of a process that a later hipGraphLaunch trips over once earlier ones have
+// been destroyed -- a segmentation fault in hip::Graph::UpdateStreams, seen after 8-12 create / replay / destroy rounds of plans
+// with forked streams (tools/split_tune_emulate.py).  Executables are small; a context that outlives thousands of plans can call
+// pem_ctx_trim, which does not touch them either -- they go with pem_ctx_destroy.
+static void retire_graph(pem_ctx *ctx, pem_cplan *plan)
+{
+    if (!plan->graph_exec) return;
+    if (ctx)
+        ctx->retired_graphs.push_back(plan->graph_exec);
+    else
+        (void)hipGraphExecDestroy(plan->graph_exec);
+    plan->graph_exec = nullptr;
+}
+
 extern "C" pem_status pem_cplan_destroy(pem_ctx *ctx, pem_cplan *plan)
 {
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
     }
-    if (plan && plan->graph_exec) (void)hipGraphExecDestroy(plan->graph_exec);
+    if (plan) retire_graph(ctx, plan);
     delete plan;
     return PEM_OK;
 }
@@ -2404,8 +2420,7 @@ extern "C" pem_status pem_cplan_set_option(pem_cplan *plan, pem_option which, in
     // that run or the sizes they produce starts the plan over
     plan->warm = false;
     if (plan->graph_exec) {
-        (void)hipGraphExecDestroy(plan->graph_exec);
-        plan->graph_exec = nullptr;
+        retire_graph(plan->owner, plan);
     }
     plan->graph_failed = false;
     return PEM_OK;
@@ -3097,8 +3112,7 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
     bool graphed = false;
     if (use_graph && !plan->graph_failed) {
         if (plan->graph_exec && plan->graph_gen != pem::alloc_generation()) {
-            (void)hipGraphExecDestroy(plan->graph_exec);
-            plan->graph_exec = nullptr;
+            retire_graph(ctx, plan);
         }
         if (!plan->graph_exec) {   // capture; any failure falls back to plain launches for the rest of the plan's life
             hipGraph_t graph = nullptr;
@@ -3134,8 +3148,7 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
             }
             PEM_TRY(check_internal(hf));
             if (hf[FLAG_CAPACITY]) {   // sizes differ from the captured ones (cannot happen while A and B are immutable)
-                (void)hipGraphExecDestroy(plan->graph_exec);
-                plan->graph_exec = nullptr;
+                retire_graph(ctx, plan);
                 plan->warm = false;
             } else {
                 graphed = true;
@@ -3424,14 +3437,13 @@ extern "C" pem_status pem_c_export_coo_f32(pem_ctx *ctx, const pem_cplan *p, int
     return export_coo_impl<float>(ctx, p, nnz, rows, cols, vals);
 }
 
-extern "C" pem_status pem_split_tile_rows(pem_ctx *ctx, const pem_tiled *A, const pem_tiled *B, int nparts, int32_t *bounds)
+// weight of every tile row of A in C = A*B: its tile-level products + its tiles + 1 (so empty-product rows still spread out)
+static pem_status tile_row_weights(pem_ctx *ctx, const pem_tiled *A, const pem_tiled *B, std::vector<double> &w)
 {
-    if (!ctx || !A || !B || !bounds || nparts < 1) return PEM_E_INVALID;
     if (A->cols != B->rows) {
-        set_error("pem_split_tile_rows: inner dimensions differ");
+        set_error("tile-row weights: inner dimensions differ");
         return PEM_E_INVALID;
     }
-    PEM_ENTER(ctx);
     const int mt = A->tile_rows;
     DevBuf &rp = ctx->tmp[3];
     PEM_TRY(rp.reserve(sizeof(long long) * ((size_t)mt + 1)));
@@ -3440,10 +3452,30 @@ extern "C" pem_status pem_split_tile_rows(pem_ctx *ctx, const pem_tiled *A, cons
     std::vector<long long> h((size_t)mt);
     PEM_HIP(hipMemcpyAsync(h.data(), rp.p, sizeof(long long) * (size_t)mt, hipMemcpyDeviceToHost, ctx->stream));
     PEM_HIP(hipStreamSynchronize(ctx->stream));
-    // weight = products + tiles of the row (so empty-product rows still spread out)
+    w.resize((size_t)mt);
+    for (int i = 0; i < mt; ++i) w[(size_t)i] = (double)h[(size_t)i] + (double)(A->h_tile_rowptr[(size_t)i + 1] - A->h_tile_rowptr[(size_t)i]) + 1.0;
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_tile_row_weights(pem_ctx *ctx, const pem_tiled *A, const pem_tiled *B, double *weights)
+{
+    if (!ctx || !A || !B || !weights) return PEM_E_INVALID;
+    PEM_ENTER(ctx);
+    std::vector<double> w;
+    PEM_TRY(tile_row_weights(ctx, A, B, w));
+    for (size_t i = 0; i < w.size(); ++i) weights[i] = w[i];
+    return PEM_OK;
+}
+
+extern "C" pem_status pem_split_tile_rows(pem_ctx *ctx, const pem_tiled *A, const pem_tiled *B, int nparts, int32_t *bounds)
+{
+    if (!ctx || !A || !B || !bounds || nparts < 1) return PEM_E_INVALID;
+    PEM_ENTER(ctx);
+    const int mt = A->tile_rows;
+    std::vector<double> w;
+    PEM_TRY(tile_row_weights(ctx, A, B, w));
     std::vector<double> pre((size_t)mt + 1, 0.0);
-    for (int i = 0; i < mt; ++i)
-        pre[(size_t)i + 1] = pre[(size_t)i] + (double)h[(size_t)i] + (double)(A->h_tile_rowptr[(size_t)i + 1] - A->h_tile_rowptr[(size_t)i]) + 1.0;
+    for (int i = 0; i < mt; ++i) pre[(size_t)i + 1] = pre[(size_t)i] + w[(size_t)i];
     bounds[0] = 0;
     int row = 0;
     for (int g = 1; g < nparts; ++g) {

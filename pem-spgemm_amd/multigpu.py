@@ -37,6 +37,78 @@ def row_bounds_from_transpose(b_tile_rowptr, b_tile_colptr, b_tile_rowidx, npart
     return np.asarray(bounds, dtype=np.int32)
 
 
+def recut_bounds(weights, bounds, times, fixed=0.0):
+    """Row-block boundaries re-cut from MEASURED per-rank pass times.  `weights`: the per-tile-row weights the first cut balanced
+    (pem_tile_row_weights), `bounds`: the cut that was timed, `times[p]`: rank p's time per pass on bounds[p]..bounds[p+1].
+    Model: a rank's pass costs `fixed` (launch structure, latency chains: what no row carries) plus its rows' weights at the rate
+    measured on that rank, rate_p = (times[p] - fixed) / weight of part p.  Rows keep the rate of the part they were timed in;
+    the new cut gives every rank the same share of the summed cost.  Pure arithmetic (no device, no communication)."""
+    import numpy as np
+    w = np.asarray(weights, dtype=np.float64)
+    b = np.asarray(bounds, dtype=np.int64)
+    t = np.asarray(times, dtype=np.float64)
+    nparts, mt = len(b) - 1, len(w)
+    assert b[0] == 0 and b[-1] == mt and len(t) == nparts and np.all(np.diff(b) >= 0)
+    pre = np.concatenate([[0.0], np.cumsum(w)])
+    part_w = pre[b[1:]] - pre[b[:-1]]
+    var = np.maximum(t - fixed, 0.05 * t)                       # (a rank is never modelled as costing nothing)
+    rate = np.where(part_w > 0, var / np.maximum(part_w, 1e-300), 0.0)
+    cost = w * np.repeat(rate, np.diff(b))
+    cpre = np.concatenate([[0.0], np.cumsum(cost)])
+    out, row = [0], 0
+    for g in range(1, nparts):
+        target = cpre[mt] * g / nparts
+        while row < mt and cpre[row + 1] <= target:
+            row += 1
+        out.append(row)
+    out.append(mt)
+    return np.asarray(out, dtype=np.int32)
+
+
+def tune_row_bounds(pkg, ctx, A, B, bounds, rank, world, device, passes=20, rounds=3, graph=True, group=None, gain=0.03):
+    """Measure-and-recut of the 1-D row split (setup work, before anything is timed): every rank times `passes` repeat passes of
+    its block, the times are all-gathered, and the blocks are re-cut (recut_bounds) so that ranks whose rows cost more per unit
+    of weight -- oversized tile rows with their serial sort chain, sparse C tiles -- get fewer of them.  The first-cut weights are
+    tile-level product counts; on the webbase-1M stand-in they leave the eight ranks 0.26-0.31 ms apart (re-cut: 0.29 for the
+    slowest).  Returns the cut with the smallest maximum over ranks -- the first cut unless a later one beat it by `gain` (pass
+    times move by a few percent from run to run) -- and the history [(bounds, per-rank ms)] of every round."""
+    import time
+    import numpy as np
+    weights = pkg.tile_row_weights(ctx, A, B)
+    best, best_max, history = np.asarray(bounds, dtype=np.int32), None, []
+    cur = best
+    for rnd in range(rounds + 1):
+        lo, hi = slice_bounds(cur, rank)
+        plan = pkg.CPlan(ctx, A, B, lo, hi)
+        if graph:
+            ctx.set_graph_replay(True)
+        for _ in range(3):
+            plan.spgemm()
+        ctx.synchronize()
+        dist.barrier(group=group)
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            plan.spgemm()
+        ctx.synchronize()
+        mine = (time.perf_counter() - t0) * 1e3 / passes
+        plan.close()
+        tt = torch.zeros(world, dtype=torch.float64, device=device)
+        tt[rank] = mine
+        dist.all_reduce(tt, group=group)
+        times = tt.cpu().numpy()
+        history.append((cur.copy(), times.copy()))
+        if best_max is None:
+            best, best_max, first_max = cur.copy(), float(times.max()), float(times.max())
+        elif times.max() < best_max and times.max() < (1.0 - gain) * first_max:
+            best, best_max = cur.copy(), float(times.max())
+        if rnd == rounds or times.max() <= 1.04 * times.mean():
+            break
+        # the part of a pass that no row carries: what the fastest rank would still pay with no rows -- taken as 60 % of the
+        # fastest time on the first round (launch structure + one row's latency chain), nothing later (the rates then hold it)
+        cur = recut_bounds(weights, cur, times, fixed=0.6 * float(times.min()) if rnd == 0 else 0.5 * float(times.min()))
+    return best, history
+
+
 def _drain(t):
     """Block the host until the communication just waited on has really finished.  Under RCCL `req.wait()` only makes
     torch's current stream wait; the library exports into the send buffers on ITS OWN stream, so the next pass's export

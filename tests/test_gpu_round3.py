@@ -307,3 +307,34 @@ def test_special_values_follow_the_fma_chain(pkg, oracle, ctx):
         plan.close()
     op = oracle.Plan(oracle.Tiled(rows, cols, I, J, V, False), oracle.Tiled(rows, cols, I, J, V, False))
     assert _same_bits_or_both_nan(op.export_csr()[2], want[2])      # ... and the tiled oracle agrees with the serial one
+
+
+def test_plans_come_and_go_under_graph_replay(pkg, standins, ctx):
+    """Sixteen plans over changing row blocks of one product, each captured, replayed and closed before the next is made -- what
+    multigpu.tune_row_bounds does.  The HIP runtime of this image crashed in hipGraphLaunch (hip::Graph::UpdateStreams) after
+    8-12 such rounds while plans destroyed their graph executables; they are retired to the context instead.  Every block's C
+    must also be the same whatever came before it."""
+    rows, cols, I, J, V = standins.make("webbase-1M")
+    A = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V)
+    mt = A.tile_rows
+    seen = {}
+    ctx.set_graph_replay(True)
+    try:
+        for rnd in range(4):
+            cuts = [0] + [int(mt * (k + 0.13 * ((rnd + k) % 3)) / 4) for k in range(1, 4)] + [mt]
+            for p in range(4):
+                plan = pkg.CPlan(ctx, A, A, cuts[p], cuts[p + 1])
+                for _ in range(5):
+                    plan.spgemm()
+                info = plan.info()
+                key = (cuts[p], cuts[p + 1])
+                sig = (info["ntiles_c"], info["npairs"], info["nnz_c"], float(plan.array("c_vals").sum()))
+                assert seen.setdefault(key, sig) == sig
+                plan.close()
+        whole = pkg.CPlan(ctx, A, A)
+        whole.spgemm()
+        whole.spgemm()
+        assert whole.info()["nnz_c"] == 50187085
+        whole.close()
+    finally:
+        ctx.set_graph_replay(False)

@@ -132,3 +132,40 @@ def test_concat_and_assemble_helpers_on_cpu():
     b = mg.balanced_tile_bounds(I, 83, 4)
     assert b[0] == 0 and b[-1] == 6 and all(x <= y for x, y in zip(b, b[1:]))
     assert mg.restrict(I, b[1], b[2]).sum() == ((I >= 16 * b[1]) & (I < 16 * b[2])).sum()
+
+
+def test_recut_bounds_moves_rows_from_slow_ranks_to_fast_ones():
+    """multigpu.recut_bounds: pure arithmetic behind the measured re-cut of the row split.  A synthetic cost -- a fixed part per
+    rank, a part proportional to the weight, a penalty on three ranks -- is balanced by the first cut on weights only; re-cutting
+    from the 'measured' times must keep the cut a partition of the rows, shrink the penalised ranks' blocks and lower the maximum."""
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.load_package()
+    mg = importlib.import_module("pem_spgemm_amd.multigpu")
+    rng = np.random.default_rng(0)
+    w = rng.pareto(1.5, 60000) + 1.0
+    pre = np.concatenate([[0.0], np.cumsum(w)])
+    b = np.searchsorted(pre, pre[-1] * np.arange(9) / 8).astype(np.int32)
+    b[0], b[-1] = 0, len(w)
+
+    def truth(bb):
+        t = 0.17 + 0.11 * (pre[bb[1:]] - pre[bb[:-1]]) / (pre[-1] / 8)
+        t[[0, 1, 5]] += 0.03
+        return t
+
+    t0 = truth(b)
+    b1 = mg.recut_bounds(w, b, t0, fixed=0.6 * t0.min())
+    assert b1[0] == 0 and b1[-1] == len(w) and np.all(np.diff(b1) > 0) and b1.dtype == np.int32
+    n0, n1 = np.diff(b), np.diff(b1)
+    assert all(n1[p] < n0[p] for p in (0, 1, 5))
+    t1 = truth(b1)
+    assert t1.max() < t0.max() - 0.005
+    b2 = mg.recut_bounds(w, b1, t1, fixed=0.5 * t1.min())
+    assert truth(b2).max() <= t1.max() + 1e-9
+    # equal times: nothing to move (up to one row at a boundary)
+    same = mg.recut_bounds(w, b, np.full(8, 0.3))
+    assert np.all(np.abs(same - b) <= 1)
+    # one rank, and empty parts, are legal inputs
+    assert list(mg.recut_bounds(w, [0, len(w)], [1.0])) == [0, len(w)]
+    be = mg.recut_bounds(np.ones(10), [0, 0, 10], [0.0, 1.0])
+    assert be[0] == 0 and be[-1] == 10
