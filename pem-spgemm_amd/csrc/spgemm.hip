@@ -197,12 +197,36 @@ __global__ void __launch_bounds__(256) s1_xl_expand_kernel(const long long *__re
         const int ha = __shfl(a, src, 64), hb0 = __shfl(b0, src, 64), hlen = __shfl(len, src, 64), hx0 = __shfl(x0, src, 64), hrow = __shfl(i, src, 64);
         const unsigned hcol = (unsigned)__shfl((int)acol, src, 64);
         int hrun = 0;
-        for (int q0 = 0; q0 < hlen; q0 += 64) {
-            const int q = q0 + lane;
-            const bool live = q < hlen && (!prune || (hcol & (b_occ[hb0 + q] >> 16)) != 0);
-            const unsigned long long bal = __ballot(live);
-            if (live) emit_product(hx0 + hrun + __popcll(bal & lt), hrow, ha, hb0 + q);
-            hrun += __popcll(bal);
+        // four trips' occupancy words (and then their tile columns) are requested together: one trip at a time the walk was a
+        // chain of 74 dependent round trips for a directory row
+        for (int q0 = 0; q0 < hlen; q0 += 256) {
+            unsigned occ[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + 64 * u + lane;
+                occ[u] = (prune && q < hlen) ? b_occ[hb0 + q] : 0xFFFF0000u;
+            }
+            bool live[4];
+            unsigned col[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + 64 * u + lane;
+                live[u] = q < hlen && (hcol & (occ[u] >> 16)) != 0;
+                col[u] = live[u] ? (unsigned)b_tile_colidx[hb0 + q] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = q0 + 64 * u + lane;
+                const unsigned long long bal = __ballot(live[u]);
+                if (live[u]) {
+                    const int x = hx0 + hrun + __popcll(bal & lt);
+                    keys[x] = local_keys ? ((uint64_t)col[u] << 32) | (uint64_t)(unsigned)x : ((uint64_t)(unsigned)hrow << bits_tc) | (uint64_t)col[u];
+                    perm[x] = (uint32_t)x;
+                    prod_a[x] = ha;
+                    prod_b[x] = hb0 + q;
+                }
+                hrun += __popcll(bal);
+            }
         }
     }
 }
@@ -257,6 +281,7 @@ __global__ void s1_c_rowptr_kernel(const int *__restrict__ c_rowidx, long long n
 // counts have been scanned.
 // ------------------------------------------------------------------------------------------
 constexpr int S1_CAP0 = 512, S1_CAP1 = 2048, S1_CAP2 = 8192, S1_CAP3 = 32768;
+constexpr int S1_NCAP0 = 2 * S1_CAP0, S1_NCAP1 = 2 * S1_CAP1;   // ... and products before pruning, for the two small bins
 constexpr int S1_RCAP0 = 256, S1_RCAP1 = 1024, S1_RCAP2 = 2048, S1_RCAP3 = 1024;   // A tiles per row a bin's LDS table holds
 constexpr int S1_COARSE = 512;   // 64-product blocks indexed per row (covers the 32768 products a 15-bit index field allows)
 
@@ -281,7 +306,7 @@ __global__ void __launch_bounds__(256) s1_reset_kernel(int *__restrict__ flags, 
 
 __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int mt,
                                                           const int *__restrict__ row_n, const int *__restrict__ row_lbase, int cap3,
-                                                          int qcap, int xlcap, int rcap2, int qcap2, int *__restrict__ row_list,
+                                                          int qcap, int xlcap, int rcap2, int qcap2, int ncap0, int ncap1, int *__restrict__ row_list,
                                                           int *__restrict__ bin_count, int *__restrict__ xl_base, int *__restrict__ row_tc,
                                                           long long *__restrict__ scalars)
 {
@@ -299,8 +324,8 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
     // bins by LIVE products (what gets sorted); the key's index field must still hold every product of the row, and the
     // bin's LDS table every A tile of the row (a row with more A tiles moves up, or to the global path)
     int bin = nl == 0 ? -1 : (n > qcap || nl > xlcap) ? 4 : nl <= S1_CAP0 ? 0 : nl <= S1_CAP1 ? 1 : nl <= S1_CAP2 ? 2 : nl <= cap3 ? 3 : 4;
-    if (bin == 0 && R > S1_RCAP0) bin = 1;
-    if (bin == 1 && R > S1_RCAP1) bin = 2;
+    if (bin == 0 && (R > S1_RCAP0 || n > ncap0)) bin = 1;
+    if (bin == 1 && (R > S1_RCAP1 || n > ncap1)) bin = 2;
     if (bin == 2 && (R > rcap2 || n > qcap2)) bin = 4;
     if (bin == 3 && R > S1_RCAP3) bin = 4;
     // slots by ballot + prefix popcount inside a wave, one LDS atomic per wave and bin inside the block, ONE global
@@ -2622,6 +2647,10 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     const int cap3 = k32 ? S1_CAP3 : S1_CAP2;
     const int qcap = k32 ? (1 << 15) - 1 : (1 << 24) - 1;
     const int xlcap = p->opt_xlcap > 0 ? p->opt_xlcap : 0x7FFFFFFF;   // test hook: rows with more live products take the global path
+    // the two small bins also bound a row's products BEFORE pruning: they are all expanded, 64 (256) per trip, and a row of 300
+    // live products among 20 000 kept its one wave busy for 60 us -- the whole kernel's time on a 1/8 row block (8-way shares of
+    // webbase-1M: 0.283 -> 0.270 ms on average; the whole matrix does not notice)
+    const int ncap0 = S1_NCAP0, ncap1 = S1_NCAP1;
     // 2^17 < tile columns < 2^19: the 8192-key bin takes 32-bit (tile column, live position) keys (see launch_rowsorts); its
     // product index lives in a 16-bit side table and its A-tile table is the smaller one
     const bool rank2 = !k32 && !p->opt_key64 && B->tile_cols < (1 << 19);
@@ -2669,7 +2698,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     // per-row tile counts are accumulated in c_tile_rowptr and scanned in place afterwards
     if (mt > 0)
         PEM_LAUNCH(ctx, s1_rowclass_kernel, grid_for((size_t)mt, 256), 256, A->tile_rowptr.as<int>(), p->tr_lo, mt, p->row_n.as<int>(),
-                   p->row_lbase.as<int>(), cap3, qcap, xlcap, rcap2, qcap2, p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(),
+                   p->row_lbase.as<int>(), cap3, qcap, xlcap, rcap2, qcap2, ncap0, ncap1, p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(),
                    p->c_tile_rowptr.as<int>(), reinterpret_cast<long long *>(ctx->d_scalars));
     // one read-back: P, the bin populations and the product total of the oversized rows
     int64_t P = 0, Pall = 0;
