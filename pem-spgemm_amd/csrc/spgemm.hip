@@ -281,7 +281,7 @@ __global__ void s1_c_rowptr_kernel(const int *__restrict__ c_rowidx, long long n
 // counts have been scanned.
 // ------------------------------------------------------------------------------------------
 constexpr int S1_CAP0 = 512, S1_CAP1 = 2048, S1_CAP2 = 8192, S1_CAP3 = 32768;
-constexpr int S1_NCAP0 = 2 * S1_CAP0, S1_NCAP1 = 2 * S1_CAP1;   // ... and products before pruning, for the two small bins
+constexpr int S1_NCAP0 = 8 * S1_CAP0, S1_NCAP1 = 8 * S1_CAP1;   // ... and products before pruning, for the two small bins
 constexpr int S1_RCAP0 = 256, S1_RCAP1 = 1024, S1_RCAP2 = 2048, S1_RCAP3 = 1024;   // A tiles per row a bin's LDS table holds
 constexpr int S1_COARSE = 512;   // 64-product blocks indexed per row (covers the 32768 products a 15-bit index field allows)
 
@@ -2648,8 +2648,9 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     const int qcap = k32 ? (1 << 15) - 1 : (1 << 24) - 1;
     const int xlcap = p->opt_xlcap > 0 ? p->opt_xlcap : 0x7FFFFFFF;   // test hook: rows with more live products take the global path
     // the two small bins also bound a row's products BEFORE pruning: they are all expanded, 64 (256) per trip, and a row of 300
-    // live products among 20 000 kept its one wave busy for 60 us -- the whole kernel's time on a 1/8 row block (8-way shares of
-    // webbase-1M: 0.283 -> 0.270 ms on average; the whole matrix does not notice)
+    // live products among 20 000 kept its one wave busy for 60 us -- the whole kernel's time on a 1/8 row block of webbase-1M.
+    // Eight times the live capacity: at twice, the 8-way shares gained most (0.283 -> 0.270 ms on average) but the band matrices,
+    // whose rows all carry 3-4 dead products per live one, moved up a bin wholesale (cage15 step 1 20.4 -> 23.9 ms)
     const int ncap0 = S1_NCAP0, ncap1 = S1_NCAP1;
     // 2^17 < tile columns < 2^19: the 8192-key bin takes 32-bit (tile column, live position) keys (see launch_rowsorts); its
     // product index lives in a 16-bit side table and its A-tile table is the smaller one
