@@ -282,6 +282,11 @@ extern "C" pem_status pem_ctx_create_on_stream(int device, void *stream, pem_ctx
         PEM_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->own_stream = true;
     }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess) ctx->cu_count = cus;
+        else (void)hipGetLastError();
+    }
     PEM_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->h_scalars), sizeof(int64_t) * 64, hipHostMallocDefault));
     {
         static_assert(NUM_FLAGS <= 16, "the flag mirror takes the last eight 64-bit slots of h_scalars");

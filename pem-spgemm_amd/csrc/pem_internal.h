@@ -181,6 +181,7 @@ struct pem_ctx {
     // pinned host page for scalar read-backs (replaces the reference's racy pageable
     // cudaMemcpyAsync of _C_nnz / d_pairs_count / C_nnz)
     std::vector<hipGraphExec_t> retired_graphs;   // graph executables plans no longer use: destroyed with the context (see retire_graph)
+    int cu_count = 0;                  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     int64_t *h_scalars = nullptr;      // 64 slots
     volatile int *h_flags = nullptr;   // the status flags of a repeat pass, written by the pass's checking thread (host view; slots 56..)
     int *h_flags_dev = nullptr;        // ... the device's address of the same words (null: not mappable, copy instead)

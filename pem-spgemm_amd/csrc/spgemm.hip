@@ -3056,7 +3056,11 @@ static pem_status step3_impl(pem_ctx *ctx, pem_cplan *p)
     const bool deep = p->npairs >= 2 * p->ntiles_c;   // two or more pairs per C tile on average (see the kernel)
     // entries per wave: 256, or 512 where the C tiles hold 8+ entries on average (see the kernel; 562 / 534 / 536 / 574 us at 256 / 512 /
     // 1024 / 2048 on the round-3 webbase-1M stand-in); PEM_OPT_S3_EPW forces 256 * value
-    const size_t s3_epw = (size_t)S3_EPW * (size_t)(p->opt_epw > 0 ? p->opt_epw : (ntc > 0 && (size_t)p->nnz_c >= 8 * ntc && !deep) ? 2 : 1);
+    // ... and only where that still leaves several rounds of waves (8 waves x 4 SIMDs per CU): a 1/8 row block of webbase-1M is
+    // 1.5 rounds at 512 entries per wave, and runs 10 % faster as three rounds of 256 (0.098 -> 0.088 ms)
+    const size_t s3_slots = (size_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 32;
+    const bool s3_many = (size_t)p->nnz_c >= 4 * s3_slots * (2 * (size_t)S3_EPW);
+    const size_t s3_epw = (size_t)S3_EPW * (size_t)(p->opt_epw > 0 ? p->opt_epw : (ntc > 0 && (size_t)p->nnz_c >= 8 * ntc && !deep && s3_many) ? 2 : 1);
     // 32-bit byte offsets on scalar bases where every array the shallow kernel touches is smaller than 4 GiB; the marked
     // entry -> tile lookup where no C tile is empty (pruned lists)
     const size_t gib4 = (size_t)1 << 32, vb = (size_t)A->value_bytes;
