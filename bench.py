@@ -62,7 +62,7 @@ def kernel_alg_bytes(name, d):
 def kernels_sha():
     """identity of the kernel sources a PMC traffic table was taken from"""
     h = hashlib.sha256()
-    for f in ("primitives.hip", "convert.hip", "spgemm.hip"):
+    for f in ("primitives.hip", "convert.hip", "step1.hip", "step2.hip", "step3.hip", "export.hip", "spgemm.hip"):
         with open(os.path.join(ROOT, "pem-spgemm_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

@@ -1,0 +1,568 @@
+// step2.hip -- rows a10 (offsets), a11, a12: C tile masks, per-tile entry counts and offsets.
+#include "spgemm_internal.h"
+
+using namespace pem;
+
+// ------------------------------------------------------------------------------------------
+// step 2
+// ------------------------------------------------------------------------------------------
+// a10 pairs_a / pairs_b (spgemm.cu:423-432): gather the expanded ids through the sort permutation
+__global__ void s2_pairs_kernel(const uint32_t *__restrict__ perm, const int *__restrict__ prod_a, const int *__restrict__ prod_b, size_t n,
+                                int *__restrict__ pairs_a, int *__restrict__ pairs_b)
+{
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint32_t q = perm[p];
+    pairs_a[p] = prod_a[q];
+    pairs_b[p] = prod_b[q];
+}
+
+// a11 (spgemm.cu:499-550).  16 lanes per C tile, lane = tile row r.  For every pair the C row
+// is OR_{kk in Amask[r]} Bmask[kk] -- work proportional to the A tile's nnz, not 16x16 ANDs.
+// Stored in the reference's packing: uint32 word q = (row 2q)<<16 | row 2q+1, i.e. the
+// uint16 at index r^1.
+__global__ void __launch_bounds__(256) s2_cmask_kernel(const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a,
+                                                       const int *__restrict__ pairs_b, long long ntc,
+                                                       const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks,
+                                                       uint16_t *__restrict__ c_mask16, int *__restrict__ c_tile_nnz)
+{
+    long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int r = threadIdx.x & 15;
+    const bool live = t < ntc;
+    unsigned cm = 0;
+    if (live) {
+        int p0 = pairs_offset[t], p1 = pairs_offset[t + 1];
+        for (int p = p0; p < p1; ++p) {
+            int a = pairs_a[p], b = pairs_b[p];
+            unsigned am = a_masks[16 * (size_t)a + r];
+            const uint16_t *bm = b_masks + 16 * (size_t)b;
+            while (am) {
+                int kk = __builtin_ctz(am);
+                am &= am - 1;
+                cm |= bm[kk];
+            }
+        }
+    }
+    int cnt = __popc(cm);
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 16);
+    if (live) {
+        c_mask16[16 * t + (r ^ 1)] = (uint16_t)cm;
+        if (r == 0) c_tile_nnz[t] = cnt;
+    }
+}
+
+// a12 (spgemm.cu:552-591): intra-tile row pointers + packed (r<<4|c) bytes
+__global__ void __launch_bounds__(256) s2_crowcol_kernel(const uint16_t *__restrict__ c_mask16, const int *__restrict__ c_tile_nnz_ptr,
+                                                         long long ntc, uint8_t *__restrict__ c_rowptr, uint8_t *__restrict__ c_rowcolidx)
+{
+    long long t = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int r = threadIdx.x & 15;
+    const bool live = t < ntc;
+    unsigned cm = live ? c_mask16[16 * t + (r ^ 1)] : 0u;
+    int cnt = __popc(cm), inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        int v = __shfl_up(inc, d, 16);
+        if (r >= d) inc += v;
+    }
+    if (!live) return;
+    int off = inc - cnt;
+    c_rowptr[16 * t + r] = (uint8_t)off;
+    uint8_t *dst = c_rowcolidx + c_tile_nnz_ptr[t] + off;
+    while (cm) {
+        int c = __builtin_ctz(cm);
+        cm &= cm - 1;
+        *dst++ = (uint8_t)((r << 4) | c);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// step 2/3, wide mappings (default).  The 16-lanes-per-tile kernels above issue one vector
+// memory instruction per 4 tiles with most lanes idle (C tiles hold ~3 entries, ~1 pair) and
+// are bound by memory-instruction issue, not bytes.  These forms give every lane a whole
+// unit of work: one C tile per lane for the masks (two 16-byte loads per operand tile, the
+// 16x16 boolean product in registers), one C entry per lane for the numeric step.
+// ------------------------------------------------------------------------------------------
+// The boolean product of one tile pair, shared by the fused step-2 kernel: B's 16 row masks are parked in LDS
+// ([dword q][lane]; a lane only ever reads what it wrote itself -- same wave, program order -- so no barrier is
+// needed) and C row r |= OR_{kk in A row r} B row kk iterates over A's nonzeros only.  Two rows share a dword
+// (w[q] = row 2q | row 2q+1 << 16, the natural uint16 layout).
+struct S2Masks {
+    uint4 A0, A1, B0, B1;   // the 16 row masks of the A tile and of the B tile, two rows per dword
+};
+__device__ __forceinline__ S2Masks s2_load_masks(const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks, const int a, const int b)
+{
+    S2Masks m;
+    m.A0 = *reinterpret_cast<const uint4 *>(a_masks + 16 * (size_t)a);
+    m.A1 = *reinterpret_cast<const uint4 *>(a_masks + 16 * (size_t)a + 8);
+    m.B0 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)b);
+    m.B1 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)b + 8);
+    return m;
+}
+__device__ __forceinline__ void s2_pair_mask(const S2Masks &m, unsigned (*bl)[256], const int tid, unsigned (&cw)[8])
+{
+    bl[0][tid] = m.B0.x; bl[1][tid] = m.B0.y; bl[2][tid] = m.B0.z; bl[3][tid] = m.B0.w;
+    bl[4][tid] = m.B1.x; bl[5][tid] = m.B1.y; bl[6][tid] = m.B1.z; bl[7][tid] = m.B1.w;
+    const unsigned aw[8] = {m.A0.x, m.A0.y, m.A0.z, m.A0.w, m.A1.x, m.A1.y, m.A1.z, m.A1.w};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        unsigned am = aw[q];            // bits 0-15: row 2q, bits 16-31: row 2q+1
+        unsigned acc = 0;
+        while (am) {                    // one iteration per nonzero of A in these two rows
+            const int bit = __builtin_ctz(am);
+            am &= am - 1;
+            const int kk = bit & 15;
+            const unsigned bwd = bl[kk >> 1][tid];            // rows kk&~1 (low half) and kk|1 (high half)
+            const unsigned brow = (kk & 1) ? (bwd >> 16) : (bwd & 0xFFFFu);
+            acc |= brow << (bit & 16);
+        }
+        cw[q] |= acc;
+    }
+}
+
+// (r<<4|c) bytes of one C tile from its masks in the natural layout (a12, spgemm.cu:582-587), row-major
+__device__ __forceinline__ void s2_emit_rowcol(const unsigned (&cw)[8], uint8_t *__restrict__ dst)
+{
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        unsigned m = cw[q] & 0xFFFFu;         // row 2q
+        while (m) {
+            const int c = __builtin_ctz(m);
+            m &= m - 1;
+            *dst++ = (uint8_t)(((2 * q) << 4) | c);
+        }
+        m = cw[q] >> 16;                      // row 2q+1
+        while (m) {
+            const int c = __builtin_ctz(m);
+            m &= m - 1;
+            *dst++ = (uint8_t)(((2 * q + 1) << 4) | c);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Step 2 (a10 offsets + a11 + a12, spgemm.cu:483-484, 499-550, 552-591) in two kernels over the row-local
+// step-1 scratch.  Step 1 leaves, for every live product slot s in [0, P): scratch_col[s] = tile column of the
+// C tile whose pair list starts there (or -1: no tile starts in this slot), scratch_off[s] = first pair of
+// that tile (a gap slot holds the end of its row's pairs, so the end of any tile's pairs is scratch_off[s+1]).
+// A row's tiles sit at the front of the row's slot range in ascending column order, so the valid slots, read
+// in slot order, ARE the C tile list in the reference's order.
+//
+// s2_tiles_kernel, one slot per lane, 256 slots per block:
+//   index   the tile's index t = number of valid slots before it = (valid slots before the block) + ballot rank.
+//           Step 1 notes for every block boundary the tile row it falls in and how far into the row's slots
+//           (block_info); with _C_rowPtr that gives the first term in three scalar loads -- no scan over slots,
+//           no dependence between blocks.
+//   mask    boolean product over the tile's pairs (two 16-byte loads per operand tile)
+//   out     _C_tileColIdx[t], pair offsets[t], Ctiles_mask[8t..] straight into the reference's dense layout --
+//           this replaces s1_compact -- and the entry count of every 256 tiles (one integer atomic per wave and
+//           group) for the entry offsets.
+// (one small scan of the 256-tile group counts in between)
+// s2_entries_kernel, one tile per lane: perTileNnz offsets from the group base + a block scan of the masks'
+//   popcounts, the (r<<4|c) bytes, and step 3's chunk index -- replacing the 3-launch scan over all tiles.
+//
+// Measured and dropped: carrying (tiles, entries) through a decoupled look-back inside ONE kernel.  Flat window
+// of 64 blocks: 1.27 ms (2000 blocks in flight = 30 round trips of ~2 us agent-scope loads behind the nearest
+// prefix); with a ticket for the block order 1.40 ms (81 k atomics on one address, 11 ns each); two-level
+// (groups of 64 blocks): 1.20 ms -- in-order completion puts every resident block behind the slowest lane of the
+// oldest one, and a lane with a 40-pair tile takes 80 us; tile counts only, published at block start: 0.94 ms
+// with every block polling from its first cycle, 0.78 ms with the look-back moved behind the mask loop; without
+// any look-back the same kernel takes 0.36 ms.
+// ------------------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ scratch_col, const int *__restrict__ scratch_off, long long nslots,
+                                                       const int2 *__restrict__ block_info, const int *__restrict__ c_rowptr,
+                                                       const int *__restrict__ pairs_a, const int *__restrict__ pairs_b,
+                                                       const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks, long long ntc,
+                                                       int *__restrict__ c_colidx, int *__restrict__ pairs_offset, uint32_t *__restrict__ c_mask,
+                                                       int *__restrict__ group_nnz, uint16_t *__restrict__ c_cnt)
+{
+    __shared__ unsigned bl[8][256];
+    __shared__ int w_tiles[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blk = blockIdx.x;
+    // valid slots before this block: the tiles of all earlier tile rows + those of the boundary row that lie before it
+    const int2 bi = block_info[blk];                         // (tile row of slot 256 blk, that slot's position in the row's range)
+    const int row_t0 = c_rowptr[bi.x], row_tiles = c_rowptr[bi.x + 1] - row_t0;
+    const long long t_blk = (long long)row_t0 + (bi.y < row_tiles ? bi.y : row_tiles);
+    const long long s = (long long)blk * 256 + tid;
+    int col = -1, p0 = 0, p1 = 0;
+    if (s < nslots) {
+        col = scratch_col[s];
+        if (col >= 0) {
+            p0 = scratch_off[s];
+            p1 = s + 1 < nslots ? scratch_off[s + 1] : (int)nslots;
+        }
+    }
+    const bool valid = col >= 0;
+    const unsigned long long vb = __ballot(valid);
+    if (lane == 0) w_tiles[wave] = __popcll(vb);
+    if (blk == 0 && tid == 0) pairs_offset[ntc] = (int)nslots;   // closing pair offset
+    __syncthreads();
+    int tile_off = __popcll(vb & ((1ull << lane) - 1ull));
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wave) tile_off += w_tiles[w];
+    const long long t = t_blk + tile_off;
+    // the masks
+    unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // natural layout: cw[q] = row 2q | row 2q+1 << 16
+    // the pair list is walked with the next pair's masks and the one after's ids already in flight: a lane's chain per pair
+    // is then one gather deep instead of two (tiles of a band times a band hold 30+ pairs)
+    if (p0 < p1) {
+        S2Masks cur = s2_load_masks(a_masks, b_masks, pairs_a[p0], pairs_b[p0]);
+        int na = 0, nb = 0;
+        if (p0 + 1 < p1) {
+            na = pairs_a[p0 + 1];
+            nb = pairs_b[p0 + 1];
+        }
+        for (int p = p0; p < p1; ++p) {
+            S2Masks nxt = cur;
+            int nna = 0, nnb = 0;
+            if (p + 1 < p1) {
+                nxt = s2_load_masks(a_masks, b_masks, na, nb);
+                if (p + 2 < p1) {
+                    nna = pairs_a[p + 2];
+                    nnb = pairs_b[p + 2];
+                }
+            }
+            s2_pair_mask(cur, bl, tid, cw);
+            cur = nxt;
+            na = nna;
+            nb = nnb;
+        }
+    }
+    int nnz_t = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) nnz_t += __popc(cw[q]);
+    const bool store = valid && t < ntc;          // (t < ntc always: both count the same valid slots)
+    // entry counts per group of S2_GROUP tiles: a wave's tiles are consecutive, so they span at most two groups
+    {
+        const long long t_first = __shfl(t, vb ? __builtin_ctzll(vb) : 0, 64);
+        const long long g0 = t_first / S2_GROUP;
+        int c0 = (store && t / S2_GROUP == g0) ? nnz_t : 0, c1 = (store && t / S2_GROUP != g0) ? nnz_t : 0;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            c0 += __shfl_xor(c0, d, 64);
+            c1 += __shfl_xor(c1, d, 64);
+        }
+        if (lane == 0 && vb) {
+            if (c0) atomicAdd(&group_nnz[g0], c0);
+            if (c1) atomicAdd(&group_nnz[g0 + 1], c1);
+        }
+    }
+    if (!store) return;
+    c_colidx[t] = col;
+    pairs_offset[t] = p0;
+    if (c_cnt) c_cnt[t] = (uint16_t)nnz_t;      // the entry offsets then come from 2 bytes per tile, not from its 32-byte mask
+    // reference packing: word q = (row 2q) << 16 | row 2q+1  (spgemm.cu:533-543)
+    *reinterpret_cast<uint4 *>(c_mask + 8 * t) = make_uint4((cw[0] << 16) | (cw[0] >> 16), (cw[1] << 16) | (cw[1] >> 16),
+                                                            (cw[2] << 16) | (cw[2] >> 16), (cw[3] << 16) | (cw[3] >> 16));
+    *reinterpret_cast<uint4 *>(c_mask + 8 * t + 4) = make_uint4((cw[4] << 16) | (cw[4] >> 16), (cw[5] << 16) | (cw[5] >> 16),
+                                                                (cw[6] << 16) | (cw[6] >> 16), (cw[7] << 16) | (cw[7] >> 16));
+}
+
+// a11's offsets + a12 (spgemm.cu:546, 1288, 552-591), one C tile per lane, S2_GROUP tiles per block: entry offsets =
+// the group's base (scanned group counts) + a block scan of the masks' popcounts; the (r<<4|c) bytes; and, for step 3,
+// the tile every S3_CHUNK-entry chunk of C starts in.
+__global__ void __launch_bounds__(S2_GROUP) s2_entries_kernel(const uint32_t *__restrict__ c_mask, long long ntc, const int *__restrict__ group_base,
+                                                              long long cap_nnz, int *__restrict__ c_tile_nnz_ptr, uint8_t *__restrict__ c_rowcolidx,
+                                                              int *__restrict__ chunk_tile, int *__restrict__ flags, WarmCheck wc,
+                                                              const long long *__restrict__ d_scalars, const int *__restrict__ bin_count)
+{
+    __shared__ int w_nnz[S2_GROUP / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // every size of the pass is final by now (the entry total came out of the group scan just before this launch): the
+    // check of a repeat pass rides along instead of taking a launch of its own at the end
+    if (wc.on && blockIdx.x == 0 && tid == 0) warm_check(wc, d_scalars, bin_count, flags);
+    const long long t = (long long)blockIdx.x * S2_GROUP + tid;
+    unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (t < ntc) {
+        const uint4 M0 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t);
+        const uint4 M1 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t + 4);
+        const unsigned w[8] = {M0.x, M0.y, M0.z, M0.w, M1.x, M1.y, M1.z, M1.w};   // word q = (row 2q) << 16 | row 2q+1
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cw[q] = (w[q] << 16) | (w[q] >> 16);          // natural layout
+    }
+    int nnz_t = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) nnz_t += __popc(cw[q]);
+    int inc = nnz_t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) w_nnz[wave] = inc;
+    __syncthreads();
+    long long off = (long long)group_base[blockIdx.x] + inc - nnz_t;
+#pragma unroll
+    for (int w = 0; w < S2_GROUP / 64; ++w)
+        if (w < wave) off += w_nnz[w];
+    if (t > ntc) return;
+    if (t == ntc) {                       // closing offset = C_nnz
+        c_tile_nnz_ptr[ntc] = (int)off;
+        return;
+    }
+    c_tile_nnz_ptr[t] = (int)off;
+    if (off + nnz_t > cap_nnz) {          // cannot happen: the host sized the buffers from the same counts
+        flags[FLAG_CAPACITY] = 1;
+        return;
+    }
+    // step 3 deals C entries in chunks of S3_CHUNK: note the tile every chunk starts in (saves its waves a search)
+    for (long long ch = (off + S3_CHUNK - 1) / S3_CHUNK; ch * S3_CHUNK < off + nnz_t; ++ch) chunk_tile[ch] = (int)t;
+    s2_emit_rowcol(cw, c_rowcolidx + off);
+}
+
+// The same offsets without the entries: where step 3 reads an entry's (row, column) off the tile's mask (DECODE below),
+// nothing on the pass needs the (r<<4|c) bytes, and the offsets come from the 2-byte entry counts s2_tiles_kernel left --
+// 39 MB in, 78 MB out on webbase-1M, where s2_entries_kernel re-reads 618 MB of masks to emit 69 MB of bytes (0.18 ms
+// against 0.03).  The bytes (Ctiles_rowColIdx, spgemm.cu:582-587) are then materialised on demand like Ctiles_rowPtr
+// (ensure_c_rowcolidx).
+__global__ void __launch_bounds__(256) s2_offsets_kernel(const uint16_t *__restrict__ c_cnt, long long ntc, const int *__restrict__ group_base,
+                                                         int *__restrict__ c_tile_nnz_ptr, int *__restrict__ chunk_tile, int *__restrict__ flags,
+                                                         WarmCheck wc, const long long *__restrict__ d_scalars, const int *__restrict__ bin_count)
+{
+    // one WAVE per group of S2_GROUP = 256 tiles, four consecutive tiles per lane (one 8-byte load, one 16-byte store): the
+    // group's base comes from the scanned group counts, so no wave waits for another (one tile per lane and a block scan
+    // took 73 us)
+    static_assert(S2_GROUP == 256, "four tiles per lane of one wave");
+    const int lane = threadIdx.x & 63;
+    const long long g = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wc.on && g == 0 && lane == 0) warm_check(wc, d_scalars, bin_count, flags);
+    const long long t = g * S2_GROUP + 4 * lane;
+    if (t > ntc) return;                                    // (only lanes above a live one leave: the scan below reads downwards)
+    int n[4] = {0, 0, 0, 0};
+    if (t + 4 <= ntc) {
+        const uint2 q = *reinterpret_cast<const uint2 *>(c_cnt + t);
+        n[0] = (int)(q.x & 0xFFFFu);
+        n[1] = (int)(q.x >> 16);
+        n[2] = (int)(q.y & 0xFFFFu);
+        n[3] = (int)(q.y >> 16);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) n[k] = t + k < ntc ? (int)c_cnt[t + k] : 0;
+    }
+    const int tsum = n[0] + n[1] + n[2] + n[3];
+    int inc = tsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    int o4[4];
+    o4[0] = group_base[g] + inc - tsum;
+    o4[1] = o4[0] + n[0];
+    o4[2] = o4[1] + n[1];
+    o4[3] = o4[2] + n[2];
+    if (t + 4 <= ntc) {
+        *reinterpret_cast<int4 *>(c_tile_nnz_ptr + t) = make_int4(o4[0], o4[1], o4[2], o4[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (t + k <= ntc) c_tile_nnz_ptr[t + k] = o4[k];             // (t + k == ntc: the closing offset = C_nnz)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (t + k >= ntc) break;
+        const long long off = o4[k];
+        for (long long ch = (off + S3_CHUNK - 1) / S3_CHUNK; ch * S3_CHUNK < off + n[k]; ++ch) chunk_tile[ch] = (int)(t + k);
+    }
+}
+
+// Ctiles_rowPtr (spgemm.cu:579-580) from the stored masks, one C tile per lane.  Nothing on the default path reads
+// it (step 3 and the export work from the masks), so it is materialised on demand: 16 bytes per C tile that the
+// mask kernel no longer writes on every pass (0.3 GB on webbase-1M).
+__global__ void __launch_bounds__(256) s2_crowptr_kernel(const uint32_t *__restrict__ c_mask, long long ntc, uint8_t *__restrict__ c_rowptr)
+{
+    long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntc) return;
+    const uint4 M0 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t);
+    const uint4 M1 = *reinterpret_cast<const uint4 *>(c_mask + 8 * t + 4);
+    const unsigned w[8] = {M0.x, M0.y, M0.z, M0.w, M1.x, M1.y, M1.z, M1.w};   // word q = (row 2q) << 16 | row 2q+1
+    unsigned rp[4] = {0, 0, 0, 0};
+    int run = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        rp[q >> 1] |= (unsigned)run << (16 * (q & 1));
+        run += __popc(w[q] >> 16);
+        rp[q >> 1] |= (unsigned)run << (16 * (q & 1) + 8);
+        run += __popc(w[q] & 0xFFFFu);
+    }
+    *reinterpret_cast<uint4 *>(c_rowptr + 16 * t) = make_uint4(rp[0], rp[1], rp[2], rp[3]);
+}
+
+pem_status pem::step2_impl(pem_ctx *ctx, pem_cplan *p)
+{
+    if (p->state < 1) {
+        set_error("pem_spgemm_step2 called before step 1");
+        return PEM_E_STATE;
+    }
+    const pem_tiled *A = p->A, *B = p->B;
+    hipStream_t st = ctx->stream;
+    const size_t n = (size_t)p->npairs, ntc = (size_t)p->ntiles_c;
+    if (!ctx->chain_events) PEM_HIP(hipEventRecord(ctx->ev[2], st));   // inside pem_spgemm the previous step's end event is the start
+    // sizing phase "C tiles"
+    PEM_TRY(arena_phase(ctx->arena, {{&p->pairs_a, sizeof(int) * (n + 4)}, {&p->pairs_b, sizeof(int) * (n + 4)},
+                                     {&p->c_mask, sizeof(uint32_t) * 8 * (ntc + 1)}, {&p->c_tile_nnz_ptr, sizeof(int) * (ntc + 4)},
+                                     {&p->c_tile_colidx, sizeof(int) * (ntc + 4)}, {&p->pairs_offset, sizeof(int) * (ntc + 4)},
+                                     {&p->group_nnz, sizeof(int) * ((ntc + S2_GROUP - 1) / S2_GROUP + 4)}}));
+    PEM_TRY(p->pairs_a.reserve(sizeof(int) * (n + 4)));
+    PEM_TRY(p->pairs_b.reserve(sizeof(int) * (n + 4)));
+    PEM_TRY(p->c_mask.reserve(sizeof(uint32_t) * 8 * (ntc + 1)));
+    PEM_TRY(p->c_tile_nnz_ptr.reserve(sizeof(int) * (ntc + 4)));
+    p->c_rowptr_valid = false;
+    // the fused kernel reads the row-local scratch of the default step 1; the global-sort step 1 (PEM_OPT_STEP1_GLOBAL_SORT)
+    // and PEM_OPT_WIDE = 0 take the 16-lanes-per-tile baseline kernels over the dense layout
+    const bool fused = p->pairs_ready && p->opt_wide;
+    p->wide = fused;
+    p->verify_folded = false;
+    p->flags_mirrored = false;
+    p->s3_decode = false;
+    p->c_rowcolidx_valid = false;
+    int64_t nnzc = 0;
+    if (fused) {
+        PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
+        PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
+        if (n > 0) {
+            // entry counts of every S2_GROUP tiles, accumulated by s2_tiles_kernel
+            const size_t nblk = (n + 255) / 256, ngroups = (ntc + S2_GROUP - 1) / S2_GROUP;
+            PEM_TRY(p->group_nnz.reserve(sizeof(int) * (ngroups + 4)));
+            // (step 1's reset clears the counters of a repeat pass; the note holds for ONE step 2 -- a second step 2 on the
+            // same step-1 result, through the step-wise API, must not add onto the scanned counts of the first)
+            if (!p->group_nnz_cleared) PEM_HIP(hipMemsetAsync(p->group_nnz.p, 0, sizeof(int) * (ngroups + 4), st));
+            p->group_nnz_cleared = false;
+            int *group_nnz = p->group_nnz.as<int>();
+            // Shallow plans (fewer than two pairs per C tile) read an entry's (row, column) off the mask in step 3, so the pass
+            // needs no (r<<4|c) bytes: offsets come from 2-byte entry counts and Ctiles_rowColIdx is materialised on demand.
+            // Deep plans keep the bytes: their many-pair kernel walks a tile's entries 64 at a time and the bytes are a small
+            // part of their traffic.
+            const bool deep = p->npairs >= 2 * p->ntiles_c;
+            const bool decode = p->opt_decode && !deep;
+            p->s3_decode = decode;
+            if (decode) PEM_TRY(p->c_tile_cnt.reserve(sizeof(uint16_t) * (ntc + 8)));
+            PEM_LAUNCH(ctx, s2_tiles_kernel, (unsigned)nblk, 256, p->scratch_col.as<int>(), p->scratch_off.as<int>(), (long long)n,
+                       p->block_info.as<int2>(), p->c_tile_rowptr.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), A->masks.as<uint16_t>(),
+                       B->masks.as<uint16_t>(), (long long)ntc, p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>(), p->c_mask.as<uint32_t>(),
+                       group_nnz, decode ? p->c_tile_cnt.as<uint16_t>() : (uint16_t *)nullptr);
+            PEM_TRY(exclusive_scan_i32(ctx, group_nnz, group_nnz, ngroups, ctx->d_scalars + 2));
+            if (p->warm_pass) {
+                nnzc = p->w_nnz;
+            } else {
+                int64_t sc[1];
+                PEM_TRY(read_scalars(ctx, ctx->d_scalars + 2, 1, sc));
+                int hf[NUM_FLAGS];
+                PEM_TRY(read_flags(ctx, hf));
+                PEM_TRY(check_internal(hf));
+                if (hf[FLAG_OVERFLOW] || sc[0] > 0x7FFFFFFFll) {
+                    set_error("step 2: C has more than 2^31-1 nonzeros, beyond the int32 range of the reference's offsets");
+                    return PEM_E_OVERFLOW;
+                }
+                nnzc = sc[0];
+            }
+            // sizing phase "C entries"
+            PEM_TRY(arena_phase(ctx->arena, {{&p->c_rowcolidx, decode ? (size_t)0 : (size_t)nnzc + 16},
+                                             {&p->s3_chunk_tile, sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)},
+                                             {&p->c_vals, (size_t)A->value_bytes * ((size_t)nnzc + 1)}}));
+            PEM_TRY(p->s3_chunk_tile.reserve(sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)));
+            WarmCheck wc = {};
+            if (p->warm_pass) wc = WarmCheck{1, p->w_P, p->w_Pall, p->w_TC, p->w_nnz, p->w_nxl, p->w_counts[0], p->w_counts[1], p->w_counts[2], p->w_counts[3], nullptr};
+            p->verify_folded = p->warm_pass;
+            // s2_offsets_kernel's checking thread is the last writer of a flag in the pass: it leaves all of them in host memory
+            if (p->warm_pass && decode && ctx->h_flags_dev) {
+                wc.host_flags = ctx->h_flags_dev;
+                p->flags_mirrored = true;
+            }
+            if (decode) {
+                PEM_LAUNCH(ctx, s2_offsets_kernel, grid_for(((ntc + S2_GROUP) / S2_GROUP) * 64, 256), 256, p->c_tile_cnt.as<uint16_t>(), (long long)ntc,
+                           group_nnz, p->c_tile_nnz_ptr.as<int>(), p->s3_chunk_tile.as<int>(), ctx->d_flags, wc,
+                           reinterpret_cast<const long long *>(ctx->d_scalars), p->bin_count.as<int>());
+                p->c_rowcolidx_valid = false;
+            } else {
+                PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
+                PEM_LAUNCH(ctx, s2_entries_kernel, (unsigned)((ntc + S2_GROUP) / S2_GROUP), S2_GROUP, p->c_mask.as<uint32_t>(), (long long)ntc, group_nnz,
+                           (long long)nnzc, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->s3_chunk_tile.as<int>(), ctx->d_flags, wc,
+                           reinterpret_cast<const long long *>(ctx->d_scalars), p->bin_count.as<int>());
+                p->c_rowcolidx_valid = true;
+            }
+            p->compact_valid = true;
+        } else {
+            PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_nnz_ptr.as<int>(), p->c_tile_nnz_ptr.as<int>(), 0, ctx->d_scalars + 2));
+            p->compact_valid = true;   // pairs_offset[0] = 0 was set by step 1's reset
+            p->c_rowcolidx_valid = true;
+        }
+    } else {
+        PEM_TRY(ensure_compact(ctx, p));
+        if (n > 0 && !p->pairs_ready)
+            PEM_LAUNCH(ctx, s2_pairs_kernel, grid_for(n, 256), 256, p->sorted_perm, p->prod_a.as<int>(), p->prod_b.as<int>(), n, p->pairs_a.as<int>(),
+                       p->pairs_b.as<int>());
+        if (ntc > 0)
+            PEM_LAUNCH(ctx, s2_cmask_kernel, grid_for(ntc * 16, 256), 256, p->pairs_offset.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
+                       (long long)ntc, A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>());
+        PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_nnz_ptr.as<int>(), p->c_tile_nnz_ptr.as<int>(), ntc, ctx->d_scalars + 2));
+        if (p->warm_pass) {
+            nnzc = p->w_nnz;
+        } else {
+            PEM_TRY(read_scalars(ctx, ctx->d_scalars + 2, 1, &nnzc));
+        }
+    }
+    if (!p->warm_pass) {
+        if (!fused) {
+            int hf[NUM_FLAGS];
+            PEM_TRY(read_flags(ctx, hf));
+            if (hf[FLAG_OVERFLOW] || nnzc > 0x7FFFFFFFll) {
+                set_error("step 2: C has more than 2^31-1 nonzeros, beyond the int32 range of the reference's offsets");
+                return PEM_E_OVERFLOW;
+            }
+        }
+        p->w_nnz = nnzc;
+    }
+    p->nnz_c = nnzc;
+    if (!(fused && p->s3_decode)) {
+        PEM_TRY(p->c_rowcolidx.reserve((size_t)nnzc + 16));
+        p->c_rowcolidx_valid = fused;       // (the baseline kernels below fill it)
+    }
+    PEM_TRY(p->s3_chunk_tile.reserve(sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)));
+    PEM_TRY(p->c_vals.reserve((size_t)A->value_bytes * ((size_t)nnzc + 1)));
+    if (ntc > 0 && !fused) {   // the 16-lanes-per-tile baseline writes Ctiles_rowPtr as it goes, like the reference (spgemm.cu:579-580)
+        PEM_TRY(p->c_rowptr.reserve(16 * (ntc + 1)));
+        PEM_LAUNCH(ctx, s2_crowcol_kernel, grid_for(ntc * 16, 256), 256, p->c_mask.as<uint16_t>(), p->c_tile_nnz_ptr.as<int>(), (long long)ntc,
+                   p->c_rowptr.as<uint8_t>(), p->c_rowcolidx.as<uint8_t>());
+        p->c_rowptr_valid = true;
+        p->c_rowcolidx_valid = true;
+    }
+    if (!ctx->capturing) PEM_HIP(hipEventRecord(ctx->ev[3], st));
+    p->state = 2;
+    return PEM_OK;
+}
+
+// Ctiles_rowPtr on demand (see s2_crowptr_kernel)
+pem_status pem::ensure_c_rowptr(pem_ctx *ctx, const pem_cplan *p)
+{
+    if (p->c_rowptr_valid || p->state < 2) return PEM_OK;
+    const size_t ntc = (size_t)p->ntiles_c;
+    PEM_ENTER(ctx);
+    PEM_TRY(p->c_rowptr.reserve(16 * (ntc + 1)));
+    if (ntc > 0) PEM_LAUNCH(ctx, s2_crowptr_kernel, grid_for(ntc, 256), 256, p->c_mask.as<uint32_t>(), (long long)ntc, p->c_rowptr.as<uint8_t>());
+    p->c_rowptr_valid = true;
+    return PEM_OK;
+}
+
+// Ctiles_rowColIdx on demand (plans whose step 3 reads the masks): the entry kernel of the other plans, run once -- it
+// recomputes the same offsets from the same scanned group counts and emits the bytes
+pem_status pem::ensure_c_rowcolidx(pem_ctx *ctx, const pem_cplan *cp)
+{
+    pem_cplan *p = const_cast<pem_cplan *>(cp);
+    if (p->c_rowcolidx_valid || p->state < 2) return PEM_OK;
+    const size_t ntc = (size_t)p->ntiles_c;
+    PEM_ENTER(ctx);
+    PEM_TRY(p->c_rowcolidx.reserve((size_t)p->nnz_c + 16));
+    if (ntc > 0) {
+        WarmCheck wc = {};
+        PEM_LAUNCH(ctx, s2_entries_kernel, (unsigned)((ntc + S2_GROUP) / S2_GROUP), S2_GROUP, p->c_mask.as<uint32_t>(), (long long)ntc,
+                   p->group_nnz.as<int>(), (long long)p->nnz_c, p->c_tile_nnz_ptr.as<int>(), p->c_rowcolidx.as<uint8_t>(), p->s3_chunk_tile.as<int>(),
+                   ctx->d_flags, wc, reinterpret_cast<const long long *>(ctx->d_scalars), p->bin_count.as<int>());
+    }
+    p->c_rowcolidx_valid = true;
+    return PEM_OK;
+}

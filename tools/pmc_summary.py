@@ -63,7 +63,7 @@ for _, k, n, d, avg in rows:
 import hashlib
 _root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _h = hashlib.sha256()
-for _f in ("primitives.hip", "convert.hip", "spgemm.hip"):
+for _f in ("primitives.hip", "convert.hip", "step1.hip", "step2.hip", "step3.hip", "export.hip", "spgemm.hip"):
     with open(os.path.join(_root, "pem-spgemm_amd", "csrc", _f), "rb") as _fh:
         _h.update(_fh.read())
 traffic["__meta__"] = dict(kernels_sha=_h.hexdigest()[:16], source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 (gfx950)")
