@@ -200,8 +200,8 @@ struct pem_ctx {
     // timing
     hipEvent_t ev[8] = {};             // step spans
     // fork/join inside a step: an independent long-tailed kernel runs on an auxiliary stream
-    hipStream_t aux[4] = {};           // [0..2]: step 1's row bins; [3]: its oversized-row chain
-    hipEvent_t ev_fork = nullptr, ev_join[4] = {};
+    hipStream_t aux[5] = {};           // [0..3]: step 1's row bins; [4]: its oversized-row chain
+    hipEvent_t ev_fork = nullptr, ev_join[5] = {};
     pem_timings timings = {};
     bool profiling = false;
     std::vector<pem::KernelStat> stats;
@@ -317,8 +317,13 @@ struct pem_cplan {
     pem::DevBuf prod_a, prod_b, aprod_off;
     pem::DevBuf lprod_off;             // like aprod_off, counting only products whose tiles can meet (live products)
     // (row-local step 1 keeps per-A-tile COUNTS in the two buffers above; only the global-sort path scans them)
-    pem::DevBuf row_n, row_lbase;      // per tile row: all products; live products -> exclusive scan = the row's first pair / C tile slot
-    pem::DevBuf xl_lrel;               // oversized rows only: live offset of every A tile relative to its row
+    pem::DevBuf row_lbase;             // per tile row: live products -> exclusive scan = the row's first pair / C tile slot
+    // the live list of step 1 (s1_expand_kernel): every live tile-level product once, in product order inside a 64-A-tile chunk
+    pem::DevBuf live_j, live_ab;       // int[cap] tile column, int2[cap] (A tile, B tile); cap = all products of the slice (w_ntotal)
+    pem::DevBuf aseg;                  // int2 per A tile of the slice: (where its live products start in the list, how many)
+    pem::DevBuf chunk_seg, chunk_n;    // per chunk: int2 (start of its stretch, live products), int64 all products
+    pem::DevBuf row_desc;              // int4 per tile row: (first piece, its length, second piece, live total) -- rows of one or two pieces
+    int64_t w_ntotal = 0;              // tile-level products of the slice, counted on the plan's first pass: the live list's capacity
     int64_t npairs_all = 0;            // all tile-level products (the reference's P) -- npairs counts the live ones
     pem::DevBuf sk0, sk1, sv0, sv1;    // sort buffers
     uint32_t *sorted_perm = nullptr;   // points into sv0/sv1
@@ -340,7 +345,7 @@ struct pem_cplan {
     bool graph_failed = false;             // capture or instantiation failed once: plain launches from then on
     bool warm = false, warm_pass = false;
     int64_t w_P = 0, w_Pall = 0, w_TC = 0, w_nnz = 0;
-    int w_counts[4] = {0, 0, 0, 0};
+    int w_counts[5] = {0, 0, 0, 0, 0};
     int64_t w_nxl = 0;
     int w_nrows_xl = 0, w_max_xl = 0;
 };

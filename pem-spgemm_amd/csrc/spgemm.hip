@@ -255,8 +255,8 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
     } chain(ctx);
     auto launch_verify = [&]() {
         if (plan->verify_folded) return;   // step 2's last kernel has already compared the sizes
-        const WarmCheck wc = {1, plan->w_P, plan->w_Pall, plan->w_TC, plan->w_nnz, plan->w_nxl, plan->w_counts[0], plan->w_counts[1],
-                              plan->w_counts[2], plan->w_counts[3], nullptr};
+        const WarmCheck wc = {1, plan->w_P, plan->w_Pall, plan->w_TC, plan->w_nnz, plan->w_nxl,
+                              {plan->w_counts[0], plan->w_counts[1], plan->w_counts[2], plan->w_counts[3], plan->w_counts[4]}, nullptr};
         PEM_LAUNCH(ctx, warm_verify_kernel, 1, 1, reinterpret_cast<const long long *>(ctx->d_scalars), plan->bin_count.as<int>(), wc, ctx->d_flags);
     };
     // Graph replay (pem_set_graph_replay): a repeat pass has fixed grids, sizes and buffer addresses, so its ~28 launches,

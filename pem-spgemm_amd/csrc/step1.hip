@@ -1,214 +1,111 @@
-// step1.hip -- row a9 + a10: the tile-level symbolic product.  Kernels and host driver of step 1 (see spgemm.hip for the
+// step1.hip -- rows a9 + a10: the tile-level symbolic product.  Kernels and host driver of step 1 (see spgemm.hip for the
 // overview of the three steps).
+//
+// Reference: SPA bitmask kernels run twice (count + emit) or the NSPARSE binned hash path (spgemm.cu:271-384, 1141-1218;
+// NSPARSE/spgemm_nsparse_kernel.h), then every C tile re-derives its pairs by binary-search intersection, twice
+// (spgemm.cu:387-497).  Here every (A tile (i,k), B tile (k,j)) IS a product of tile row i keyed by j, so grouping a row's
+// products by j yields the C tile list and the pair lists, in ascending k, in one pass.
+//
+// Round 4 layout of the default path (three phases, the row sorts concurrent):
+//   s1_expand_kernel     one wave per 64 consecutive A tiles of the slice: every product is formed and tested ONCE (the A
+//                        tile's occupied columns against the B tile's occupied rows); the live ones are written, in product
+//                        order, to the wave's own stretch of a scratch list (tile column | A tile, B tile) -- so a tile row's
+//                        live products are one or two contiguous pieces (one per 64-tile chunk the row touches)
+//   s1_rowclass_kernel   per tile row: live total from the pieces, size class
+//   (scan of the totals: where the row's pairs go)
+//   s1_tiny_kernel / s1_rowsort_kernel<...>   per row: load the live keys (coalesced), sort by tile column, stream out the
+//                        sorted pairs and the C tile list of the row
+// Rounds 1-3 counted the live products in one kernel and expanded + tested them AGAIN inside the row sorts (68 % of webbase-1M's
+// products are dead, 83 % of scircuit's: the sort kernels spent a third to a half of their instructions on products they then
+// dropped, and the bins had to bound a row's products BEFORE pruning).
 #include "spgemm_internal.h"
 
 using namespace pem;
 
 // ------------------------------------------------------------------------------------------
-// step 1
+// global expand + radix sort ("esc"): PEM_OPT_STEP1_GLOBAL_SORT, the A/B baseline of step 1
 // ------------------------------------------------------------------------------------------
-// per A tile (i,k): number of tiles in B's tile row k (= tile-level intermediate products;
-// the quantity of spgemm_nsparse_kernel.h:135-151 per A tile instead of per row)
+// per A tile (i,k): number of tiles in B's tile row k (= tile-level intermediate products; the quantity of
+// spgemm_nsparse_kernel.h:135-151 per A tile instead of per row), and how many of them are live.
 // A product (A tile (i,k), B tile (k,j)) can only contribute if some column occupied in the A tile is a row
 // occupied in the B tile.  The reference's tile-level symbolic product keeps every product and so
 // materialises pairs -- and whole C tiles -- that stay empty (83 % of the pairs of the scircuit stand-in).
 // With prune != 0 those dead products are dropped here, before anything is sorted or stored: the final C
 // is unchanged, only the intermediate C tile / pair lists lose their empty members.  prune == 0 reproduces
-// the reference's lists exactly.  16 lanes per A tile: aprod = all products, lprod = live products.
+// the reference's lists exactly.  8 lanes per A tile: aprod = all products, lprod = live products.
 __global__ void __launch_bounds__(256) s1_aprod_kernel(const int *__restrict__ a_tile_colidx, const uint32_t *__restrict__ a_occ, int a_lo,
                                                        int nA, const int *__restrict__ b_tile_rowptr, const uint32_t *__restrict__ b_occ,
-                                                       int prune, int *__restrict__ aprod, int *__restrict__ lprod,
-                                                       const long long *__restrict__ a_tile_keys, int tr_lo, int *__restrict__ row_n,
-                                                       int *__restrict__ row_l)
+                                                       int prune, int *__restrict__ aprod, int *__restrict__ lprod)
 {
-    constexpr int G = 8;        // lanes per A tile (B tile rows average ~34 tiles; 16 lanes: 88 us, 8: 59 us, 4: 58 us)
+    constexpr int G = 8;
     const int arel = (blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int l = threadIdx.x & (G - 1);
     const bool in = arel < nA;
-    constexpr int LONG = 64 * G;   // a B tile row this long is walked by the whole wave, not by the tile's G lanes
-    int len = 0, cnt = 0, b0 = 0;
-    unsigned acol = 0;
+    int len = 0, cnt = 0;
     if (in) {
         const int k = a_tile_colidx[a_lo + arel];
-        b0 = b_tile_rowptr[k];
+        const int b0 = b_tile_rowptr[k];
         len = b_tile_rowptr[k + 1] - b0;
         if (prune) {
-            acol = a_occ[a_lo + arel] & 0xFFFFu;
-            if (len < LONG) {
+            const unsigned acol = a_occ[a_lo + arel] & 0xFFFFu;
 #pragma unroll 4
-                for (int q = l; q < len; q += G) cnt += (acol & (b_occ[b0 + q] >> 16)) != 0;
-            }
+            for (int q = l; q < len; q += G) cnt += (acol & (b_occ[b0 + q] >> 16)) != 0;
         }
     }
 #pragma unroll
     for (int d = G / 2; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, G);
-    if (prune) {
-        // hub rows of B (4 700 tiles on webbase-1M): left to 8 lanes, one such A tile kept its wave busy for 590 trips and
-        // the kernel waited for it (80 us, 60 of them this tail); the wave takes them together, 64 tiles per trip
-        const int lane = threadIdx.x & 63;
-        unsigned long long todo = __ballot(in && l == 0 && len >= LONG);
-        while (todo) {
-            const int src = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const int hb0 = __shfl(b0, src, 64), hlen = __shfl(len, src, 64);
-            const unsigned hcol = (unsigned)__shfl((int)acol, src, 64);
-            int c = 0;
-#pragma unroll 4
-            for (int q = lane; q < hlen; q += 64) c += (hcol & (b_occ[hb0 + q] >> 16)) != 0;
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
-            if ((lane & ~(G - 1)) == src) cnt = c;   // every lane of the tile's group holds its count
-        }
-    }
     if (!prune) cnt = len;
     if (in && l == 0) {
         aprod[arel] = len;
         lprod[arel] = cnt;
     }
-    // Per tile-row totals (row-local step 1: the rows' product counts are all the scan that is left -- the offsets of
-    // the A tiles inside a row are rebuilt in LDS by the row's own workgroup).  The wave's eight A tiles are
-    // consecutive, so tiles of one row sit next to each other: the first of each run adds the run's sums, one atomic
-    // pair per run (a hub row of 4 700 A tiles: 590 adds on its two counters instead of 4 700).
-    if (row_n == nullptr) return;
-    const int row = in ? (int)(a_tile_keys[a_lo + arel] >> 32) - tr_lo : -1 - (int)(threadIdx.x / G);   // distinct dummies never merge
-    const int lane = threadIdx.x & 63;
-    // suffix sums over the run, by doubling: tiles are sorted by row, so "the tile d further on has my row" implies the
-    // ones in between have it too, and its partial sum only ever covers tiles of that same row
-    int sum_n = len, sum_l = cnt;
-#pragma unroll
-    for (int d = 1; d < 64 / G; d <<= 1) {
-        const int src = lane + d * G;
-        const int orow = __shfl(row, src & 63, 64), on = __shfl(sum_n, src & 63, 64), ol = __shfl(sum_l, src & 63, 64);
-        if (src < 64 && orow == row) {
-            sum_n += on;
-            sum_l += ol;
-        }
-    }
-    const int prow = __shfl(row, (lane - G) & 63, 64);
-    const bool head = in && l == 0 && (lane < G || prow != row);
-    if (head) {
-        atomicAdd(&row_n[row], sum_n);
-        atomicAdd(&row_l[row], sum_l);
-    }
 }
 
 // global expand (16 lanes per A tile walk B's tile row k): live products only, compacted by ballot;
-// product x gets key (i - tr_lo, j).  xl_base == nullptr: every row (PEM_STEP1=esc), positions = global
-// live offsets; else only the oversized rows (xl_base[i] >= 0), positions relative to the row's slot.
-__global__ void __launch_bounds__(256) s1_xl_expand_kernel(const long long *__restrict__ a_tile_keys, const int *__restrict__ a_tile_rowptr,
-                                                           const uint32_t *__restrict__ a_occ, int a_lo, int nA, int tr_lo,
-                                                           const int *__restrict__ lprod_off, const int *__restrict__ xl_base,
-                                                           const int *__restrict__ b_tile_rowptr, const int *__restrict__ b_tile_colidx,
-                                                           const uint32_t *__restrict__ b_occ, int prune, int bits_tc,
-                                                           uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, int *__restrict__ prod_a,
-                                                           int *__restrict__ prod_b, int local_keys, const int *__restrict__ xl_rows)
+// product x gets key (i - tr_lo, j), positions = global live offsets
+__global__ void __launch_bounds__(256) s1_esc_expand_kernel(const long long *__restrict__ a_tile_keys, const uint32_t *__restrict__ a_occ, int a_lo,
+                                                            int nA, int tr_lo, const int *__restrict__ lprod_off,
+                                                            const int *__restrict__ b_tile_rowptr, const int *__restrict__ b_tile_colidx,
+                                                            const uint32_t *__restrict__ b_occ, int prune, int bits_tc,
+                                                            uint64_t *__restrict__ keys, uint32_t *__restrict__ perm, int *__restrict__ prod_a,
+                                                            int *__restrict__ prod_b)
 {
-    // xl_rows != nullptr: a two-dimensional grid over the oversized rows only -- blockIdx.y picks the row, blockIdx.x sixteen of
-    // its A tiles (the grid covers the plan's longest tile row; blocks past a row's end leave at once) -- instead of one pass
-    // over every A tile of the slice, of which all but the few oversized rows' exit after two loads
-    int arel;
-    bool in;
-    if (xl_rows) {
-        const int xi = xl_rows[blockIdx.y];
-        const int r0 = a_tile_rowptr[tr_lo + xi] - a_lo, r1 = a_tile_rowptr[tr_lo + xi + 1] - a_lo;
-        arel = r0 + (int)blockIdx.x * 16 + (int)(threadIdx.x >> 4);
-        in = arel < r1;
-    } else {
-        arel = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-        in = arel < nA;
-    }
+    const int arel = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const bool in = arel < nA;
     const int l = threadIdx.x & 15, grp = (threadIdx.x & 63) >> 4;
-    int a = 0, i = 0, k = 0, x0 = -1, b0 = 0, len = 0;
+    int a = 0, i = 0, x0 = 0, b0 = 0, len = 0;
     unsigned acol = 0xFFFFu;
     if (in) {
         a = a_lo + arel;
         const long long ak = a_tile_keys[a];
         i = (int)(ak >> 32) - tr_lo;
-        k = (int)(ak & 0xFFFFFFFFll);
-        if (xl_base) {          // lprod_off: live offsets relative to the row (s1_xl_rel_kernel), only valid in oversized rows
-            const int base = xl_base[i];
-            if (base >= 0) x0 = base + lprod_off[arel];
-        } else {                // global live offsets (PEM_STEP1=esc)
-            x0 = lprod_off[arel];
-        }
-        if (x0 >= 0) {
-            b0 = b_tile_rowptr[k];
-            len = b_tile_rowptr[k + 1] - b0;
-            if (prune) acol = a_occ[a] & 0xFFFFu;
-        }
+        const int k = (int)(ak & 0xFFFFFFFFll);
+        x0 = lprod_off[arel];
+        b0 = b_tile_rowptr[k];
+        len = b_tile_rowptr[k + 1] - b0;
+        if (prune) acol = a_occ[a] & 0xFFFFu;
     }
-    // the four 16-lane groups of a wave walk different B rows: iterate to the longest, compact per group.  A B tile row of
-    // 256+ tiles (a directory page of webbase-1M: 4 700) is left out of that walk -- sixteen lanes took 294 dependent trips
-    // over it and the whole grid waited (121 us for 1.6 M products) -- and walked by the whole wave afterwards.
-    constexpr int XL_LONG = 256;
-    const bool is_long = len >= XL_LONG;
-    const int glen = is_long ? 0 : len;
-    int maxlen = glen;
+    // the four 16-lane groups of a wave walk different B rows: iterate to the longest, compact per group
+    int maxlen = len;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         const int o = __shfl_xor(maxlen, d, 64);
         maxlen = o > maxlen ? o : maxlen;
     }
     const uint64_t hi = (uint64_t)(unsigned)i << bits_tc;
-    auto emit_product = [&](const int x, const int row_hi_src, const int aa, const int bb) {
-        const uint64_t hh = (uint64_t)(unsigned)row_hi_src << bits_tc;
-        const unsigned col = (unsigned)b_tile_colidx[bb];
-        keys[x] = local_keys ? ((uint64_t)col << 32) | (uint64_t)(unsigned)x : hh | (uint64_t)col;
-        perm[x] = (uint32_t)x;
-        prod_a[x] = aa;
-        prod_b[x] = bb;
-    };
-    (void)hi;
     int run = 0;
     for (int q0 = 0; q0 < maxlen; q0 += 16) {
         const int q = q0 + l;
-        const bool live = q < glen && (!prune || (acol & (b_occ[b0 + q] >> 16)) != 0);
+        const bool live = q < len && (!prune || (acol & (b_occ[b0 + q] >> 16)) != 0);
         const unsigned m16 = (unsigned)(__ballot(live) >> (16 * grp)) & 0xFFFFu;
-        // (keys: local_keys -> (tile column, position) for the per-row sort of s1_xl_rowsort_kernel -- a row's products already
-        // sit in the row's own stretch of the buffers, in product order; else (row, tile column) for the global sort)
-        if (live) emit_product(x0 + run + __popc(m16 & ((1u << l) - 1u)), i, a, b0 + q);
-        run += __popc(m16);
-    }
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    unsigned long long todo = __ballot(l == 0 && is_long && x0 >= 0);
-    while (todo) {                                              // wave-uniform
-        const int src = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const int ha = __shfl(a, src, 64), hb0 = __shfl(b0, src, 64), hlen = __shfl(len, src, 64), hx0 = __shfl(x0, src, 64), hrow = __shfl(i, src, 64);
-        const unsigned hcol = (unsigned)__shfl((int)acol, src, 64);
-        int hrun = 0;
-        // four trips' occupancy words (and then their tile columns) are requested together: one trip at a time the walk was a
-        // chain of 74 dependent round trips for a directory row
-        for (int q0 = 0; q0 < hlen; q0 += 256) {
-            unsigned occ[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = q0 + 64 * u + lane;
-                occ[u] = (prune && q < hlen) ? b_occ[hb0 + q] : 0xFFFF0000u;
-            }
-            bool live[4];
-            unsigned col[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = q0 + 64 * u + lane;
-                live[u] = q < hlen && (hcol & (occ[u] >> 16)) != 0;
-                col[u] = live[u] ? (unsigned)b_tile_colidx[hb0 + q] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = q0 + 64 * u + lane;
-                const unsigned long long bal = __ballot(live[u]);
-                if (live[u]) {
-                    const int x = hx0 + hrun + __popcll(bal & lt);
-                    keys[x] = local_keys ? ((uint64_t)col[u] << 32) | (uint64_t)(unsigned)x : ((uint64_t)(unsigned)hrow << bits_tc) | (uint64_t)col[u];
-                    perm[x] = (uint32_t)x;
-                    prod_a[x] = ha;
-                    prod_b[x] = hb0 + q;
-                }
-                hrun += __popcll(bal);
-            }
+        if (live) {
+            const int x = x0 + run + __popc(m16 & ((1u << l) - 1u));
+            keys[x] = hi | (uint64_t)(unsigned)b_tile_colidx[b0 + q];
+            perm[x] = (uint32_t)x;
+            prod_a[x] = a;
+            prod_b[x] = b0 + q;
         }
+        run += __popc(m16);
     }
 }
 
@@ -248,78 +145,344 @@ __global__ void s1_c_rowptr_kernel(const int *__restrict__ c_rowidx, long long n
         for (int row = tr + 1; row <= mt; ++row) c_rowptr[row] = (int)ntc;
 }
 
-
 // ------------------------------------------------------------------------------------------
-// step 1, row-local form (default).  The products of one tile row of A only ever meet
-// products of the same row, so the grouping by C tile is a per-row sort on the tile column:
-// one workgroup expands the row's live products into LDS as (tile col, product index) keys,
-// sorts them there and streams the sorted pair list out once -- no global sort passes.  Rows
-// are binned by their LIVE product count: <=512 one wave and <=2048 four waves (bitonic network
-// in registers), <=8192 and <=32768 sixteen waves (keys kept in product order + a stable LDS
-// radix sort on the column bits); larger rows take the global expand/radix-sort path above.
-// C tile columns and per-tile pair offsets go to row-local scratch (a row has at most as many
-// C tiles as products) and are compacted into the reference layout once the per-row tile
-// counts have been scanned.
+// default path, phase 1: expansion.  One 512-thread workgroup per CHUNK of S1_CH = 512 consecutive A tiles of the slice (a
+// chunk may span several tile rows, a tile row several chunks).  The chunk's products -- A tile by A tile, each A tile's B tile
+// row in order -- form one sequence of N_b products; thread a tables where A tile a's products end in it (block scan of the B
+// row lengths), its first B tile and its occupied columns.  The eight waves then walk the sequence together, iteration k (256
+// products: four trips of 64) by wave k mod 8: the A tiles a trip covers are read off the table with a scalar cursor (no search:
+// v_readlane of the table window the lanes hold), the four B-side gathers go out together, every product is tested ONCE, and the
+// live ones are compacted by ballot.  Where an iteration's live products go depends on how many came before it: that count is
+// handed from iteration to iteration through LDS (t_cum; the wave of iteration k waits for the word iteration k - 1 leaves
+// behind -- all eight waves are resident, so the chain always advances), which keeps the chunk's live products contiguous and in
+// PRODUCT ORDER however the waves interleave:
+//     lj[x] = tile column j of the product,  lab[x] = (A tile, B tile)
+// The chunk's stretch of the list is N_b slots (ALL its products -- known after the block scan, so the block takes its place
+// with ONE atomic before it has tested anything); the live products fill its front.  Per A tile the kernel leaves where its
+// live products start and how many they are (aseg; read off the trips' ballots afterwards), per chunk the same (chunk_seg): a
+// tile row's live products are the concatenation of one piece per chunk it touches, each piece contiguous.
+// A hub -- an A tile whose B tile row holds thousands of tiles, webbase-1M's directory pages -- is thereby spread over the
+// eight waves (one wave per 64 A tiles walked a chunk with three of them for 105 us, of a kernel that should take 40).
+// The first block also clears the pass's status words (flags, bin populations, scalars): nothing in this kernel reads or
+// sets them, and every later kernel of the pass comes after it -- the pass needs no reset launch.
 // ------------------------------------------------------------------------------------------
-constexpr int S1_CAP0 = 512, S1_CAP1 = 2048, S1_CAP2 = 8192, S1_CAP3 = 32768;
-constexpr int S1_NCAP0 = 8 * S1_CAP0, S1_NCAP1 = 8 * S1_CAP1;   // ... and products before pruning, for the two small bins
-constexpr int S1_RCAP0 = 256, S1_RCAP1 = 1024, S1_RCAP2 = 2048, S1_RCAP3 = 1024;   // A tiles per row a bin's LDS table holds
-constexpr int S1_COARSE = 512;   // 64-product blocks indexed per row (covers the 32768 products a 15-bit index field allows)
+constexpr int S1_CH = 512;               // A tiles per chunk
+constexpr int S1_XW = 8;                 // waves of the expansion's workgroup (= S1_CH / 64)
+constexpr int S1_XU = 4;                 // trips (64 products each) per iteration
+constexpr int S1_XTRIPS = 2048;          // trips per epoch: LDS holds one ballot and one running count per trip (131 072 products; longer chunks take several epochs)
+constexpr unsigned S1_SENT = 0xFFFFFFFFu;
+constexpr int S1_CAP0 = 64, S1_CAP1 = 512, S1_CAP2 = 2048, S1_CAP3 = 8192, S1_CAP4 = 32768;   // live products per row of a bin
+constexpr int S1_QB0 = 6, S1_QB1 = 9, S1_QB2 = 11, S1_QB3 = 13, S1_QB4 = 15;                  // ... and the bits of a key's index field
+constexpr int S1_NLIST = 6;              // row lists: the five bins + the oversized rows
+constexpr int S1_PC1 = 64, S1_PC2 = 256, S1_PC3 = 1024;   // pieces (chunks) per row a bin's table holds (= its threads)
 
-__global__ void __launch_bounds__(256) s1_reset_kernel(int *__restrict__ flags, int *__restrict__ bin_count, long long *__restrict__ scalars,
-                                                       int *__restrict__ pairs_offset, int *__restrict__ row_tc, int mt, int *__restrict__ row_n,
-                                                       int *__restrict__ row_l, int *__restrict__ group_nnz, int ngroups)
+__global__ void __launch_bounds__(256) s1_total_kernel(const int *__restrict__ a_tile_colidx, int a_lo, int nA, const int *__restrict__ b_tile_rowptr,
+                                                       unsigned long long *__restrict__ total)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < NUM_FLAGS) flags[i] = 0;
-    if (i < 8) bin_count[i] = 0;
-    if (i < 4) scalars[i] = 0;
-    if (i == 0) {
-        pairs_offset[0] = 0;
-        row_tc[mt] = 0;
+    // all tile-level products of the slice (the reference's P): the capacity of the live list, first pass of a plan only
+    const int arel = blockIdx.x * blockDim.x + threadIdx.x;
+    long long len = 0;
+    if (arel < nA) {
+        const int k = a_tile_colidx[a_lo + arel];
+        len = b_tile_rowptr[k + 1] - b_tile_rowptr[k];
     }
-    if (i <= mt) {              // per-row product totals, accumulated by s1_aprod_kernel
-        row_n[i] = 0;
-        row_l[i] = 0;
-    }
-    if (i < ngroups) group_nnz[i] = 0;   // entry counts per S2_GROUP tiles, accumulated by s2_tiles_kernel (repeat passes: size known)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) len += __shfl_xor(len, d, 64);
+    if ((threadIdx.x & 63) == 0 && len) atomicAdd(total, (unsigned long long)len);
 }
 
-__global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int mt,
-                                                          const int *__restrict__ row_n, const int *__restrict__ row_lbase, int cap3,
-                                                          int qcap, int xlcap, int rcap2, int qcap2, int ncap0, int ncap1, int *__restrict__ row_list,
+#ifdef PEM_S1_DEBUG
+__device__ unsigned long long g_k1dbg[32768][8];   // per chunk: start, after the allocation, end (100 MHz), products; summed over its iterations: walk, gather, chain wait, stores
+extern "C" void pem_debug_k1(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k1dbg), sizeof(unsigned long long) * 32768 * 8); }
+#endif
+
+// inclusive prefix sum over the wave's 64 lanes on the vector ALU's data-parallel-primitive paths (row shifts inside the rows of
+// sixteen, then the two row broadcasts): six instructions, no LDS
+__device__ __forceinline__ int s1_wave_inclusive_scan_dpp(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2 and 3
+    return v;
+}
+
+__global__ void __launch_bounds__(64 * S1_XW) s1_expand_kernel(const int *__restrict__ a_tile_colidx, const uint32_t *__restrict__ a_occ, int a_lo, int nA,
+                                                               const int *__restrict__ b_tile_rowptr, const int2 *__restrict__ b_colocc, int prune,
+                                                               int *__restrict__ bin_count, unsigned long long cap, int2 *__restrict__ aseg,
+                                                               int2 *__restrict__ chunk_seg, long long *__restrict__ chunk_n, int *__restrict__ lj,
+                                                               int2 *__restrict__ lab, int *__restrict__ flags, long long *__restrict__ scalars)
+{
+    static_assert(S1_CH == 64 * S1_XW, "one thread per A tile of the chunk");
+    __shared__ unsigned t_end[S1_CH];                 // A tile a's products are [t_end[a - 1], t_end[a]) of the chunk's sequence
+    __shared__ uint2 t_pay[S1_CH];                    // (d, occupied columns of A tile a): B tile of product q of A tile a = q + d
+    __shared__ unsigned t_hist[S1_XW][64];            // per wave: how many A tiles end at each product of the trip in hand
+    __shared__ unsigned long long t_bal[S1_XTRIPS];   // per trip of the epoch: its live products
+    __shared__ unsigned t_cum[S1_XTRIPS + 1];         // ... and the chunk's live products before it (S1_SENT: not known yet)
+    __shared__ unsigned s_wsum[S1_XW];
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = (int)blockIdx.x;
+    if (c == 0) {
+        if (tid < NUM_FLAGS) flags[tid] = 0;
+        if (tid < BC_FAULT) bin_count[tid] = 0;
+        if (tid < 4) scalars[tid] = 0;
+    }
+#ifdef PEM_S1_DEBUG
+    const unsigned long long dbg0 = wall_clock64();
+#endif
+    const int arel = c * S1_CH + tid;
+    const bool in = arel < nA;
+    int b0 = 0;
+    unsigned len = 0, acol = 0xFFFFu;
+    if (in) {
+        const unsigned ao = a_occ[a_lo + arel];                  // (requested with the tile column, not behind it)
+        const int k = a_tile_colidx[a_lo + arel];
+        b0 = b_tile_rowptr[k];
+        len = (unsigned)(b_tile_rowptr[k + 1] - b0);
+        if (prune) acol = ao & 0xFFFFu;
+    }
+    unsigned inc = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = (unsigned)__shfl_up((int)inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    unsigned wpre = 0, N_b = 0;                                  // (host: the slice holds fewer than 2^32 products, so 32 bits do)
+#pragma unroll
+    for (int w = 0; w < S1_XW; ++w) {
+        if (w < wave) wpre += s_wsum[w];
+        N_b += s_wsum[w];
+    }
+    inc += wpre;
+    t_end[tid] = inc;
+    t_pay[tid] = make_uint2((unsigned)(b0 - (int)(inc - len)), acol);
+    if (tid == 0) s_base = N_b ? atomicAdd(reinterpret_cast<unsigned long long *>(bin_count + BC_BUMP), (unsigned long long)N_b) : 0ull;
+    __syncthreads();
+    // (cannot fail while A and B are what the list was sized from; if it does the chunk contributes nothing, the pass's sizes
+    // come out wrong and the row classification raises FLAG_CAPACITY)
+    const unsigned long long base64 = s_base;
+    const bool ok = base64 + (unsigned long long)N_b <= cap;
+    if (!ok && tid == 0) bin_count[BC_FAULT] = 1;
+    const unsigned base = (unsigned)base64;
+#ifdef PEM_S1_DEBUG
+    const unsigned long long dbg1 = wall_clock64();
+#endif
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned st_a = tid ? t_end[tid - 1] : 0u, en_a = inc;   // my A tile's products
+    unsigned my_pos = 0, my_cnt = 0;                               // ... and, filled in epoch by epoch, where its live ones start and how many they are
+    unsigned carry = 0;                                            // live products of the earlier epochs
+    const unsigned N_run = ok ? N_b : 0u;
+    for (unsigned e0 = 0; e0 < N_run; e0 += 64u * S1_XTRIPS) {
+        const unsigned left = N_run - e0;
+        const int ntr = left >= 64u * S1_XTRIPS ? S1_XTRIPS : (int)((left + 63u) >> 6);
+        const int nit = (ntr + S1_XU - 1) / S1_XU;
+        for (int x = tid; x <= ntr; x += 64 * S1_XW) t_cum[x] = x == 0 ? carry : S1_SENT;
+        __syncthreads();
+        for (int k = wave; k < nit; k += S1_XW) {
+            const unsigned qb0 = e0 + 256u * (unsigned)k;
+#ifdef PEM_S1_DEBUG
+            const unsigned long long dt0 = wall_clock64();
+#endif
+            // the A tile holding product qb0: the first whose products end beyond it (wave-uniform search over the table)
+            int a = 0;
+#pragma unroll
+            for (int step = S1_CH / 2; step > 0; step >>= 1)
+                if (t_end[a + step - 1] <= qb0) a += step;
+            a = __builtin_amdgcn_readfirstlane(a);
+            // The A tile of every product of a trip, without a search: the tile of product q is a + #{tiles a' >= a whose products end at or
+            // before q}.  The lanes, as A TILES a + lane, drop a count at the position their products end (if inside the trip); the lanes, as
+            // PRODUCTS, read the counts back and prefix-sum them (six DPP steps).  Five LDS operations and ~25 vector instructions per
+            // trip however many A tiles it spans (a six-step shuffle search per product made the LDS crossbar the kernel's bound, a
+            // scalar walk over the tiles its instruction issue: 18 instructions per A tile and trip).
+            int bb[S1_XU], aa[S1_XU];
+            unsigned ac[S1_XU];
+            volatile unsigned *hist = t_hist[wave];
+#pragma unroll
+            for (int u = 0; u < S1_XU; ++u) {
+                const unsigned qb = qb0 + 64u * (unsigned)u, q = qb + (unsigned)lane;
+                bb[u] = 0;
+                aa[u] = 0;
+                ac[u] = 0;
+                if (qb >= N_run) continue;                       // (wave-uniform)
+                int ta = 0;                                      // tiles ending at or before my product, over the windows walked
+                for (;;) {
+                    hist[lane] = 0;
+                    const unsigned ve = a + lane < S1_CH ? t_end[a + lane] : 0xFFFFFFFFu;
+                    const unsigned m = ve - qb;                  // (tiles before the cursor end at or before qb: none is in the window)
+                    if (m < 64u) __hip_atomic_fetch_add(&hist[m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    const int incl = s1_wave_inclusive_scan_dpp((int)hist[lane]);
+                    ta += incl;
+                    const int done = __builtin_amdgcn_readlane(incl, 63);
+                    a += done;
+                    if (done < 64 || a >= S1_CH) break;          // (64: every tile of the window ended inside the trip -- empty B rows; next window)
+                }
+                // (ta counts the tiles that END at or before q: my tile is the next one.  The cursor for the next trip is already there.)
+                const int mine = (a - __builtin_amdgcn_readlane(ta, 63)) + ta;
+                aa[u] = mine < S1_CH ? mine : S1_CH - 1;
+                const uint2 pay = t_pay[aa[u]];
+                bb[u] = (int)q + (int)pay.x;
+                ac[u] = pay.y;
+            }
+#ifdef PEM_S1_DEBUG
+            const unsigned long long dt1 = wall_clock64();
+#endif
+            int2 co[S1_XU];
+#pragma unroll
+            for (int u = 0; u < S1_XU; ++u) co[u] = b_colocc[qb0 + 64u * (unsigned)u + (unsigned)lane < N_run ? bb[u] : 0];   // (unconditional: the four gathers go out together)
+            unsigned long long bal[S1_XU];
+            int cnt[S1_XU];
+#pragma unroll
+            for (int u = 0; u < S1_XU; ++u) {
+                const bool live = qb0 + 64u * (unsigned)u + (unsigned)lane < N_run && (!prune || (ac[u] & ((unsigned)co[u].y >> 16)) != 0);
+                bal[u] = __ballot(live);
+                cnt[u] = __popcll(bal[u]);
+            }
+#ifdef PEM_S1_DEBUG
+            const unsigned long long dt2 = wall_clock64();
+#endif
+            // the chunk's live products before this iteration: left behind by the wave of iteration k - 1
+            unsigned before = 0;
+            if (lane == 0) {
+                while ((before = __hip_atomic_load(&t_cum[S1_XU * k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == S1_SENT) __builtin_amdgcn_s_sleep(1);
+                unsigned run = before;
+#pragma unroll
+                for (int u = 0; u < S1_XU; ++u) {
+                    if (S1_XU * k + u < ntr) {
+                        t_bal[S1_XU * k + u] = bal[u];
+                        run += (unsigned)cnt[u];
+                        __hip_atomic_store(&t_cum[S1_XU * k + u + 1], run, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            before = (unsigned)__builtin_amdgcn_readfirstlane((int)before);
+#ifdef PEM_S1_DEBUG
+            const unsigned long long dt3 = wall_clock64();
+#endif
+            unsigned x0 = base + before;
+#pragma unroll
+            for (int u = 0; u < S1_XU; ++u) {
+                if ((bal[u] >> lane) & 1ull) {
+                    const unsigned x = x0 + (unsigned)__popcll(bal[u] & lt);
+                    lj[x] = co[u].x;
+                    lab[x] = make_int2(a_lo + c * S1_CH + aa[u], bb[u]);
+                }
+                x0 += (unsigned)cnt[u];
+            }
+#ifdef PEM_S1_DEBUG
+            if (lane == 0 && c < 32768) {
+                const unsigned long long dt4 = wall_clock64();
+                atomicAdd(&g_k1dbg[c][4], dt1 - dt0);
+                atomicAdd(&g_k1dbg[c][5], dt2 - dt1);
+                atomicAdd(&g_k1dbg[c][6], dt3 - dt2);
+                atomicAdd(&g_k1dbg[c][7], dt4 - dt3);
+            }
+#endif
+        }
+        __syncthreads();
+        // my A tile's live products in this epoch, read off the trips' ballots: lp(x) = live products of the chunk before product x
+        const unsigned e1 = e0 + 64u * (unsigned)ntr;
+        auto lp = [&](unsigned x) {
+            const unsigned r = (x - e0) >> 6, o = (x - e0) & 63u;
+            return t_cum[r] + (o ? (unsigned)__popcll(t_bal[r] & ((1ull << o) - 1ull)) : 0u);
+        };
+        const bool last_epoch = e1 >= N_run;
+        if (st_a >= e0 && (st_a < e1 || (last_epoch && st_a == e1))) my_pos = lp(st_a < e1 ? st_a : e1);
+        {
+            const unsigned lo = st_a > e0 ? st_a : e0, hi = en_a < e1 ? en_a : e1;
+            if (hi > lo) my_cnt += lp(hi) - lp(lo);
+        }
+        carry = t_cum[ntr];
+        __syncthreads();                                         // the epoch's words are re-armed by the next one
+    }
+    if (st_a > N_run) my_pos = carry;                            // (only when the chunk was skipped: every position collapses onto its start)
+    if (N_run == 0) my_pos = 0;
+    if (in) aseg[arel] = make_int2((int)(base + my_pos), (int)my_cnt);
+    if (tid == 0) {
+        chunk_seg[c] = make_int2((int)base, (int)carry);
+        chunk_n[c] = (long long)N_b;
+#ifdef PEM_S1_DEBUG
+        if (c < 32768) {
+            g_k1dbg[c][0] = dbg0;
+            g_k1dbg[c][1] = dbg1;
+            g_k1dbg[c][2] = wall_clock64();
+            g_k1dbg[c][3] = (unsigned long long)N_b;
+        }
+#endif
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// phase 2: per tile row, the live total (from the pieces) and the size class.  Rows are binned by LIVE products -- what gets
+// sorted -- and by the number of pieces the bin's table holds: <= 64 live in at most two pieces: one wave, one key per lane
+// (s1_tiny_kernel); <= 512 one wave, <= 2048 four waves (bitonic network in registers); <= 8192 and <= 32768 sixteen waves
+// (stable LDS radix sort on the column bits); above that one workgroup per row with the keys in global memory.
+// Also: the 64-bit total of ALL products (the reference's P, summed from the chunks), the closing words of the pass's arrays,
+// step 2's group counters, and the re-arming of the live list's allocator for the next pass.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict__ a_tile_rowptr, int tr_lo, int a_lo, int mt, int nchunks,
+                                                          const int2 *__restrict__ aseg, const int2 *__restrict__ chunk_seg,
+                                                          const long long *__restrict__ chunk_n, int tiny_ok, int cap4, int xlcap,
+                                                          int *__restrict__ row_l, int4 *__restrict__ row_desc, int *__restrict__ row_list,
                                                           int *__restrict__ bin_count, int *__restrict__ xl_base, int *__restrict__ row_tc,
-                                                          long long *__restrict__ scalars)
+                                                          long long *__restrict__ scalars, int *__restrict__ flags, int *__restrict__ pairs_offset,
+                                                          int *__restrict__ group_nnz, int ngroups)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    int n = 0, nl = 0, R = 0;
+    int nl = 0, np = 0;
     if (i < mt) {
-        R = a_tile_rowptr[tr_lo + i + 1] - a_tile_rowptr[tr_lo + i];
-        n = row_n[i];
-        nl = row_lbase[i + 1] - row_lbase[i];
+        const int ra0 = a_tile_rowptr[tr_lo + i] - a_lo, ra1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
+        unsigned pos0 = 0, pos1 = 0;
+        int cnt0 = 0;
+        if (ra1 > ra0) {
+            const int c0 = ra0 / S1_CH, c1 = (ra1 - 1) / S1_CH;
+            np = c1 - c0 + 1;
+            const int2 f0 = aseg[ra0];
+            pos0 = (unsigned)f0.x;
+            if (np == 1) {
+                const int2 e = aseg[ra1 - 1];
+                cnt0 = (int)((unsigned)e.x + (unsigned)e.y - pos0);
+                nl = cnt0;
+            } else {
+                const int2 e0 = aseg[c0 * S1_CH + S1_CH - 1], f1 = aseg[c1 * S1_CH], e1 = aseg[ra1 - 1];
+                cnt0 = (int)((unsigned)e0.x + (unsigned)e0.y - pos0);
+                pos1 = (unsigned)f1.x;
+                long long tot = (long long)cnt0 + (long long)((unsigned)e1.x + (unsigned)e1.y - pos1);
+                for (int c = c0 + 1; c < c1; ++c) tot += chunk_seg[c].y;          // (independent loads: a directory row of webbase-1M spans 74 chunks)
+                nl = tot > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)tot;                  // (beyond int32 the scan of the totals reports the overflow)
+            }
+        }
+        row_l[i] = nl;
+        row_desc[i] = make_int4((int)pos0, cnt0, (int)pos1, nl);
         xl_base[i] = -1;
         row_tc[i] = 0;
     }
-    // bins by LIVE products (what gets sorted); the key's index field must still hold every product of the row, and the
-    // bin's LDS table every A tile of the row (a row with more A tiles moves up, or to the global path)
-    int bin = nl == 0 ? -1 : (n > qcap || nl > xlcap) ? 4 : nl <= S1_CAP0 ? 0 : nl <= S1_CAP1 ? 1 : nl <= S1_CAP2 ? 2 : nl <= cap3 ? 3 : 4;
-    if (bin == 0 && (R > S1_RCAP0 || n > ncap0)) bin = 1;
-    if (bin == 1 && (R > S1_RCAP1 || n > ncap1)) bin = 2;
-    if (bin == 2 && (R > rcap2 || n > qcap2)) bin = 4;
-    if (bin == 3 && R > S1_RCAP3) bin = 4;
+    int bin = -1;
+    if (nl > 0) {
+        bin = 5;
+        if (nl <= S1_CAP0 && np <= 2 && tiny_ok) bin = 0;
+        else if (nl <= S1_CAP1 && np <= S1_PC1) bin = 1;
+        else if (nl <= S1_CAP2 && np <= S1_PC2) bin = 2;
+        else if (nl <= S1_CAP3 && np <= S1_PC3) bin = 3;
+        else if (nl <= cap4 && np <= S1_PC3) bin = 4;
+        if (nl > xlcap) bin = 5;                                 // test hook: rows above xlcap live products take the oversized-row path
+    }
     // slots by ballot + prefix popcount inside a wave, one LDS atomic per wave and bin inside the block, ONE global
-    // atomic per block and bin (order inside a bin is irrelevant): 4 k wave-level atomics on four counters serialised
-    // for ~20 us of a 33 us kernel
-    __shared__ int blk_cnt[5], blk_base[5];
+    // atomic per block and bin (order inside a bin is irrelevant)
+    __shared__ int blk_cnt[S1_NLIST], blk_base[S1_NLIST];
     __shared__ long long blk_all;
-    if (threadIdx.x < 5) blk_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < S1_NLIST) blk_cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) blk_all = 0;
     __syncthreads();
     int wbase = 0, rank = 0;
 #pragma unroll
-    for (int b = 0; b < 5; ++b) {
+    for (int b = 0; b < S1_NLIST; ++b) {
         const unsigned long long m = __ballot(bin == b);
         if (m == 0) continue;
         const int leader = __builtin_ctzll(m);
@@ -332,59 +495,27 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
         }
     }
     {   // every tile-level product of the slice (the reference's P), 64-bit: one atomic per block
-        long long wn = n;
+        long long wn = i < nchunks ? chunk_n[i] : 0;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) wn += __shfl_xor(wn, d, 64);
         if (lane == 0 && wn) atomicAdd(reinterpret_cast<unsigned long long *>(&blk_all), (unsigned long long)wn);
     }
     __syncthreads();
-    if (threadIdx.x < 5) blk_base[threadIdx.x] = blk_cnt[threadIdx.x] ? atomicAdd(&bin_count[threadIdx.x], blk_cnt[threadIdx.x]) : 0;
+    if (threadIdx.x < S1_NLIST) blk_base[threadIdx.x] = blk_cnt[threadIdx.x] ? atomicAdd(&bin_count[threadIdx.x], blk_cnt[threadIdx.x]) : 0;
     if (threadIdx.x == 0 && blk_all) atomicAdd(reinterpret_cast<unsigned long long *>(&scalars[3]), (unsigned long long)blk_all);
     __syncthreads();
     if (bin >= 0) row_list[(size_t)bin * mt + blk_base[bin] + wbase + rank] = i;
-    if (bin == 4) {                                             // oversized rows are few
-        xl_base[i] = atomicAdd(&bin_count[5], nl);
-        atomicMax(&bin_count[6], nl);                           // the largest of them decides between the per-row and the global sort
+    if (bin == 5) {                                              // oversized rows are few
+        xl_base[i] = atomicAdd(&bin_count[BC_XL_TOTAL], nl);
+        atomicMax(&bin_count[BC_XL_MAX], nl);
     }
-}
-
-// oversized rows: live-product offsets of the row's A tiles relative to the row, one 1024-thread block per row (a directory
-// row of webbase-1M has 4 700 A tiles: five trips; with 256 threads it took nineteen, 16 us on a chain that is the critical
-// path of a rank's share of an 8-way split)
-__global__ void __launch_bounds__(1024) s1_xl_rel_kernel(const int *__restrict__ xl_rows, int nrows_xl, const int *__restrict__ a_tile_rowptr, int tr_lo,
-                                                         int a_lo, const int *__restrict__ lcnt, int *__restrict__ lrel)
-{
-    constexpr int WAVES = 16;
-    __shared__ int wsum[WAVES];
-    __shared__ int carry_s;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int li = blockIdx.x; li < nrows_xl; li += gridDim.x) {
-        const int i = xl_rows[li];
-        const int a0 = a_tile_rowptr[tr_lo + i] - a_lo, a1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
-        if (threadIdx.x == 0) carry_s = 0;
-        __syncthreads();
-        for (int x0 = a0; x0 < a1; x0 += 1024) {
-            const int x = x0 + threadIdx.x;
-            const int c = x < a1 ? lcnt[x] : 0;
-            int inc = c;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_up(inc, d, 64);
-                if (lane >= d) inc += o;
-            }
-            if (lane == 63) wsum[wave] = inc;
-            __syncthreads();
-            int woff = carry_s, tot = 0;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) {
-                if (w < wave) woff += wsum[w];
-                tot += wsum[w];
-            }
-            if (x < a1) lrel[x] = woff + inc - c;
-            __syncthreads();
-            if (threadIdx.x == 0) carry_s += tot;
-            __syncthreads();
-        }
+    for (int g = i; g < ngroups; g += gridDim.x * blockDim.x) group_nnz[g] = 0;   // step 2's entry counts per S2_GROUP tiles (repeat passes: size known)
+    if (i == 0) {
+        pairs_offset[0] = 0;
+        row_tc[mt] = 0;
+        if (bin_count[BC_FAULT]) flags[FLAG_CAPACITY] = 1;       // a chunk found no room in the live list (see s1_expand_kernel)
+        bin_count[BC_FAULT] = 0;
+        *reinterpret_cast<unsigned long long *>(bin_count + BC_BUMP) = 0ull;   // the next pass's expansion starts from an empty list
     }
 }
 
@@ -468,135 +599,74 @@ __device__ __forceinline__ void s1_bitonic_regs(KeyT (&v)[EPT], KeyT *lds, const
     for (int m = 0; m < EPT; ++m) lds[reverse ? (THREADS * EPT - 1 - ((tid << LOGE) | m)) : ((tid << LOGE) | m)] = v[m];
     __syncthreads();
 }
+// ------------------------------------------------------------------------------------------
+// phase 3: the row sorts.  A row's live products arrive as (tile column, position in the row's live list) keys; equal tile
+// columns stay in list (= product = ascending k) order because the position is part of the key, or -- the sixteen-wave bins --
+// because the keys sit in list order and the radix sort on the column bits is stable.  The sorted stream is written once:
+// pairs_a / pairs_b (final), and per distinct tile column (= C tile) its column + first pair into the row's SLOTS
+// (scratch_col / scratch_off; a row has at most as many C tiles as live products; the slots behind the last tile are marked and
+// carry the end of the row's pairs), the row's tile count, and for every 256-slot boundary inside the row's range the pair
+// (row, position) -- block_info, which is what lets step 2 index C tiles densely without scanning the slots.
+// ------------------------------------------------------------------------------------------
+// rows of at most 64 live products in at most two pieces: one wave, one key per lane, everything in registers
+__global__ void __launch_bounds__(256) s1_tiny_kernel(const int *__restrict__ row_list, int nrows_bin, const int4 *__restrict__ row_desc,
+                                                      const int *__restrict__ row_lbase, const int *__restrict__ lj, const int2 *__restrict__ lab,
+                                                      int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ scratch_col,
+                                                      int *__restrict__ scratch_off, int2 *__restrict__ block_info, int *__restrict__ row_tc)
+{
+    const int lane = threadIdx.x & 63;
+    const int li = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (li >= nrows_bin) return;                                 // (wave-uniform)
+    const int i = __builtin_amdgcn_readfirstlane(row_list[li]);
+    const int4 d = row_desc[i];                                  // (first piece, its length, second piece, live total)
+    const int lp0 = row_lbase[i], nl = d.w;
+    const bool valid = lane < nl;
+    unsigned key = 0xFFFFFFFFu;
+    int2 ab = make_int2(0, 0);
+    if (valid) {
+        const unsigned src = lane < d.y ? (unsigned)d.x + (unsigned)lane : (unsigned)d.z + (unsigned)(lane - d.y);
+        key = ((unsigned)lj[src] << S1_QB0) | (unsigned)lane;
+        ab = lab[src];
+    }
+    // bitonic network over the wave's 64 keys (the padding key sorts to the end)
+#pragma unroll
+    for (int kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+        for (int jj = kk >> 1; jj > 0; jj >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)key, jj, 64);
+            const bool lower = (lane & jj) == 0, up = (lane & kk) == 0;
+            key = ((key < o) == (lower == up)) ? key : o;
+        }
+    }
+    const int j = (int)(key >> S1_QB0), from = (int)(key & 63u);
+    const int a = __shfl(ab.x, from, 64), b = __shfl(ab.y, from, 64);
+    const int jprev = __shfl_up(j, 1, 64);
+    const bool head = valid && (lane == 0 || jprev != j);        // (sorted: the nl live keys are the first nl lanes)
+    const unsigned long long bal = __ballot(head);
+    const int tiles = __popcll(bal);
+    if (valid) {
+        pairs_a[lp0 + lane] = a;
+        pairs_b[lp0 + lane] = b;
+        if (head) {
+            const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+            scratch_col[lp0 + rank] = j;
+            scratch_off[lp0 + rank] = lp0 + lane;
+        }
+        if (lane >= tiles) {                                     // the row's slots behind its last tile start no tile
+            scratch_col[lp0 + lane] = -1;
+            scratch_off[lp0 + lane] = lp0 + nl;
+        }
+    }
+    if (lane == 0) {
+        const long long bb = ((long long)lp0 + 255) / 256;       // at most one block boundary of step 2 falls inside 64 slots
+        if (bb * 256 < (long long)lp0 + nl) block_info[bb] = make_int2(i, (int)(bb * 256 - lp0));
+        row_tc[i] = tiles;
+    }
+}
 
-template <typename KeyT, int CAP, int QB, int THREADS, int RCAP, bool RANK = false>
+template <typename KeyT, int CAP, int QB, int THREADS>
 struct S1Row {
     KeyT *keys;
-    uint16_t *qmap;                // RANK: product index of the key at every live position (the key carries the position)
-    const int *roff, *rbs;
-    const unsigned *rco;           // occupied columns of every A tile of the row (pruning)
-    const int *cstart;             // A tile holding product 64*c, for every 64th product (rows of up to 32768 products)
-    bool coarse;
-    // (the one-wave bin has few A tiles per row: its search is short)
-    static constexpr bool COARSE_OK = THREADS >= 256;
-    static constexpr bool ORDERED = THREADS == 1024;   // live keys compacted in product order (see expand_compact)
-    int R, a0, n, a_lo, prune;
-    const int2 *b_colocc;          // per B tile: (tile column, occupancy word) -- one 8-byte gather gives the key and the pruning test
-    struct Product {
-        int a, b;          // operand tile ids
-        unsigned acol;     // occupied columns of the A tile
-    };
-    // by value: address-taken locals would put the kernel on a scratch (private memory) segment
-    __device__ __forceinline__ Product tile_b(int q, bool want_acol) const
-    {
-        Product r;
-        int ar;
-        r.acol = 0xFFFFu;
-        if (COARSE_OK && coarse) {   // a short walk from the tile of the 64-product block instead of a log2(R)-step search
-            ar = cstart[q >> 6];
-            while (roff[ar + 1] <= q) ++ar;
-        } else {
-            ar = s1_find_a(roff, 0, R, q);
-        }
-        r.b = rbs[ar] + (q - roff[ar]);
-        if (want_acol) r.acol = rco[ar];
-        r.a = a_lo + a0 + ar;
-        return r;
-    }
-    // key of product q: (tile col, q); a product whose tiles cannot meet gets the padding key and sorts to the end
-    __device__ __forceinline__ KeyT product_key(int q) const
-    {
-        if (q >= n) return ~KeyT(0);
-        const Product pr = tile_b(q, prune != 0);
-        const int2 co = b_colocc[pr.b];
-        if (prune && !(pr.acol & ((unsigned)co.y >> 16))) return ~KeyT(0);
-        if constexpr (RANK) return KeyT(co.x) << QB;        // the low bits take the key's live position (expand_compact)
-        return (KeyT(co.x) << QB) | KeyT(q);
-    }
-    // expand all n products of the row, keep the live ones: their keys are packed into keys[0..nlive) in
-    // arbitrary order (ballot + one LDS atomic per wave and chunk) -- the sort that follows fixes the order,
-    // and only live keys get sorted.  Returns nlive; keys[nlive..npad_to) are set to the padding key.
-    __device__ __forceinline__ int expand_compact(const int tid, int *s_cnt, int npad_to_mult, int *ordcnt) const
-    {
-        const int lane = tid & 63, wave = tid >> 6;
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        // four chunks per trip: their table searches and B-side gathers are independent and overlap; the
-        // compaction follows once the keys are in registers
-        constexpr int U = 4;
-        if constexpr (ORDERED) {
-            // 16-wave bins keep the live keys in PRODUCT ORDER (chunk, wave, lane ascending), so that a stable sort on
-            // the tile column alone finishes the job: every (chunk, wave) posts its live count, a barrier, and each
-            // wave adds up the counts in front of it (at most 64 LDS reads)
-            constexpr int WAVES = THREADS / 64;
-            int total = 0;
-            for (int q0 = 0; q0 < n; q0 += U * THREADS) {
-                KeyT key[U];
-                unsigned long long bal[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) key[u] = product_key(q0 + u * THREADS + tid);
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    bal[u] = __ballot(key[u] != ~KeyT(0));
-                    if (lane == 0) ordcnt[u * WAVES + wave] = __popcll(bal[u]);
-                }
-                __syncthreads();
-                int c = lane < U * WAVES ? ordcnt[lane] : 0;          // U * WAVES = 64 counts, one per lane
-                int inc = c;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int o = __shfl_up(inc, d, 64);
-                    if (lane >= d) inc += o;
-                }
-                const int trip_total = __shfl(inc, 63, 64);
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int base = total + __shfl(inc - c, u * WAVES + wave, 64);
-                    if (key[u] != ~KeyT(0)) {
-                        const int pos = base + __popcll(bal[u] & lt);
-                        if constexpr (RANK) {
-                            // RANK keys: (tile column, live position).  Product order = position order, so the stable sort on
-                            // the column bits still yields ascending k inside a C tile; the product index -- which needs up to
-                            // 16 bits and would push a 19-bit tile column past 32 -- waits in a 2-byte side table
-                            keys[pos] = key[u] | KeyT(pos);
-                            qmap[pos] = (uint16_t)(q0 + u * THREADS + tid);
-                        } else {
-                            keys[pos] = key[u];
-                        }
-                    }
-                }
-                total += trip_total;
-                __syncthreads();                                      // the counts are re-posted by the next trip
-            }
-            if (tid == 0) *s_cnt = total;
-        } else {
-            // ballot + one LDS atomic per wave and chunk: arbitrary order, the full-key sort that follows fixes it
-            for (int q0 = 0; q0 < n; q0 += U * THREADS) {
-                KeyT key[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) key[u] = product_key(q0 + u * THREADS + tid);
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const bool live = key[u] != ~KeyT(0);
-                    const unsigned long long bal = __ballot(live);
-                    if (bal) {
-                        int base = 0;
-                        const int leader = __builtin_ctzll(bal);
-                        if (lane == leader) base = atomicAdd(s_cnt, __popcll(bal));
-                        base = __shfl(base, leader, 64);
-                        if (live) keys[base + __popcll(bal & lt)] = key[u];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        const int nlive = *s_cnt;
-        int upto = npad_to_mult;               // THREADS * 2^e >= nlive: what the register sort will load
-        while (upto < nlive) upto <<= 1;
-        if (upto > CAP) upto = CAP;
-        for (int x = nlive + tid; x < upto; x += THREADS) keys[x] = ~KeyT(0);
-        __syncthreads();
-        return nlive;
-    }
     // lanes of the wave holding the same 8-bit digit as this one (among the valid lanes)
     static __device__ __forceinline__ unsigned long long match_digit(const bool valid, const unsigned d)
     {
@@ -624,8 +694,8 @@ struct S1Row {
             __syncthreads();
             // digit counts (keys read straight from LDS: they are only held in registers for the scatter below, which
             // keeps 32 key registers from living across the scan).  One LDS atomic per key, except where the whole
-            // round holds one digit (the product-index bits of neighbouring products, already grouped columns) -- 64
-            // atomics on one counter serialise, so there the first lane adds the round's population instead
+            // round holds one digit (already grouped columns) -- 64 atomics on one counter serialise, so there the first
+            // lane adds the round's population instead
 #pragma unroll
             for (int r = 0; r < EPT; ++r) {
                 const bool valid = r < rpw && e0 + r * 64 < n;
@@ -699,10 +769,8 @@ struct S1Row {
 
 #ifdef PEM_S1_DEBUG
 // diagnostic build only (make EXTRA=-DPEM_S1_DEBUG): phase clocks of the row-sort bins, spread over 1024 slots per
-// bin so the bookkeeping atomics do not serialise; [bin][slot][stage, expand, sort, emit, rows, max row, -, -]
+// bin so the bookkeeping atomics do not serialise; [bin][slot][pieces, load, sort, emit, rows, max row, -, -]
 __device__ unsigned long long g_s1dbg[4][1024][8];
-__device__ unsigned long long g_s1blk[4][1024][4];   // first 1024 blocks of every bin: start, end, HW_ID, XCC_ID
-extern "C" void pem_debug_s1_blocks(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s1blk), sizeof(unsigned long long) * 4 * 1024 * 4); }
 #define S1_DBG_MARK(k)                                                   \
     do {                                                                 \
         __syncthreads();                                                 \
@@ -732,31 +800,25 @@ extern "C" void pem_debug_s1(unsigned long long *out32, int reset)
 #define S1_DBG_MARK(k)
 #endif
 
-template <typename KeyT, int CAP, int QB, int THREADS, int RCAP, bool RANK = false>
-__global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || sizeof(KeyT) == 8 ? 4 : 8) : 1) s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr,
-                                                             int tr_lo, int a_lo, const int *__restrict__ a_tile_colidx,
-                                                             const int *__restrict__ acnt, const int *__restrict__ row_n, const int *__restrict__ row_lbase,
-                                                             const int *__restrict__ b_tile_rowptr, const int2 *__restrict__ b_colocc,
-                                                             const uint32_t *__restrict__ a_occ, int prune,
-                                                             int *__restrict__ pairs_a, int *__restrict__ pairs_b,
-                                                             int *__restrict__ scratch_col, int *__restrict__ scratch_off,
-                                                             int2 *__restrict__ block_info, int *__restrict__ row_tc, int key_bits)
+// bins 1-4: one wave / 256 / 1024 / 1024 threads per tile row.  The row's pieces (one per chunk of A tiles it touches: where
+// the piece lies in the live list, where it goes in the row's list) are tabled in LDS -- one per thread, one trip -- and the
+// keys are loaded piece by piece, coalesced; the emit finds a sorted key's (A tile, B tile) through the same table.
+template <typename KeyT, int CAP, int QB, int THREADS>
+__global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || sizeof(KeyT) == 8 ? 4 : 8) : 1)
+    s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr, int tr_lo, int a_lo,
+                      const int2 *__restrict__ aseg, const int *__restrict__ row_lbase, const int *__restrict__ lj, const int2 *__restrict__ lab,
+                      int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ scratch_col, int *__restrict__ scratch_off,
+                      int2 *__restrict__ block_info, int *__restrict__ row_tc, int key_bits)
 {
     constexpr int LOGT = THREADS == 64 ? 6 : THREADS == 256 ? 8 : 10;
-    constexpr int EMAX = CAP / THREADS;
+    constexpr int EMAX = CAP / THREADS, WAVES = THREADS / 64;
     static_assert(EMAX == 8 || EMAX == 32, "a bin sorts up to 8 (or, for the largest, 32) keys per thread");
+    static_assert(CAP <= (1 << QB), "the key's index field holds every position of the row's list");
     __shared__ KeyT keys[CAP];
-    __shared__ int roff[RCAP + 1];     // product offset of every A tile of the row, relative to the row
-    __shared__ int rbs[RCAP];          // first B tile id of that A tile's B tile row
-    __shared__ unsigned rco[RCAP];     // occupied columns of that A tile
-    __shared__ int wsum[THREADS / 64];
-    __shared__ int s_cnt;
-    static_assert(!RANK || (THREADS == 1024 && CAP <= (1 << QB) && sizeof(KeyT) == 4), "rank keys: ordered compaction, position fits the low bits");
-    __shared__ uint16_t qmap[RANK ? CAP : 1];
-    constexpr bool COARSE = S1Row<KeyT, CAP, QB, THREADS, RCAP, RANK>::COARSE_OK;
-    __shared__ int cstart[COARSE ? S1_COARSE : 1];
-    __shared__ unsigned radix_hist[THREADS == 1024 ? (THREADS / 64) * 256 : 1];   // digit counters of the radix sort (16-wave bins)
-    __shared__ int ordcnt[64];                                                   // live counts per (chunk, wave) of the ordered compaction
+    __shared__ unsigned psrc[THREADS];   // piece p of the row: where it lies in the live list ...
+    __shared__ int pdst[THREADS + 1];    // ... and where it goes in the row's list (exclusive scan of the piece lengths)
+    __shared__ int wsum[WAVES];
+    __shared__ unsigned radix_hist[THREADS == 1024 ? WAVES * 256 : 1];   // digit counters of the radix sort (16-wave bins)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
 #ifdef PEM_S1_DEBUG
@@ -769,74 +831,57 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
         if (tid == 0) dbg_t = wall_clock64();      // 100 MHz
         const unsigned long long dbg_row0 = dbg_t;
 #endif
-        if (tid == 0) s_cnt = 0;
-        S1Row<KeyT, CAP, QB, THREADS, RCAP, RANK> row;
-        row.keys = keys;
-        row.qmap = qmap;
-        row.roff = roff;
-        row.rbs = rbs;
-        row.rco = rco;
-        row.prune = prune;
-        row.a_lo = a_lo;
-        row.b_colocc = b_colocc;
-        row.a0 = a_tile_rowptr[tr_lo + i] - a_lo;
-        row.R = a_tile_rowptr[tr_lo + i + 1] - a_lo - row.a0;   // <= RCAP: the row classification saw to that
-        row.n = row_n[i];
+        const int ra0 = a_tile_rowptr[tr_lo + i] - a_lo, ra1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
+        const int lp0 = row_lbase[i], nl = row_lbase[i + 1] - lp0;
+        const int c0 = ra0 / S1_CH, np = (ra1 - 1) / S1_CH - c0 + 1;       // <= THREADS: the row classification saw to that
         {
-            // the row's A-tile table: product counts -> offsets relative to the row (exclusive scan, THREADS entries per
-            // trip -- one trip for all but hub rows), first B tile, occupied columns
-            int carry = 0;
-            for (int x0 = 0; x0 < row.R; x0 += THREADS) {
-                const int x = x0 + tid;
-                int c = 0;
-                if (x < row.R) {
-                    const int a = a_lo + row.a0 + x;
-                    c = acnt[row.a0 + x];
-                    rbs[x] = b_tile_rowptr[a_tile_colidx[a]];
-                    rco[x] = a_occ[a] & 0xFFFFu;
-                }
-                int inc = c;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const int o = __shfl_up(inc, d, 64);
-                    if (lane >= d) inc += o;
-                }
-                int ex = carry + inc - c;
-                if (THREADS > 64 && row.R - x0 > 64) {   // (block-uniform) this trip's entries spill over the first wave
-                    if (lane == 63) wsum[wave] = inc;
-                    __syncthreads();
-                    int tot = 0;
-#pragma unroll
-                    for (int w = 0; w < THREADS / 64; ++w) {
-                        if (w < wave) ex += wsum[w];
-                        tot += wsum[w];
-                    }
-                    carry += tot;
-                    __syncthreads();                      // wsum is re-posted by the next trip
-                } else {
-                    carry += __shfl(inc, 63, 64);         // only wave 0 holds entries; THREADS == 64: the wave's total
-                }
-                if (x < row.R) roff[x] = ex;
+            unsigned src = 0;
+            int cnt = 0;
+            if (tid < np) {
+                const int c = c0 + tid;
+                const int first = ra0 > c * S1_CH ? ra0 : c * S1_CH, last = (ra1 < c * S1_CH + S1_CH ? ra1 : c * S1_CH + S1_CH) - 1;
+                const int2 s = aseg[first], e = aseg[last];
+                src = (unsigned)s.x;
+                cnt = (int)((unsigned)e.x + (unsigned)e.y - src);
             }
-            if (tid == 0) roff[row.R] = row.n;
-        }
-        row.cstart = cstart;
-        row.coarse = COARSE && row.n <= 64 * S1_COARSE;
-        __syncthreads();
-        if (row.coarse) {
-            for (int x = tid; x < row.R; x += THREADS) {      // every 64-product block start inside this A tile's range
-                const int lo = roff[x], hi = roff[x + 1];
-                for (int c = (lo + 63) >> 6; (c << 6) < hi; ++c) cstart[c] = x;
+            int inc = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += o;
             }
+            int ex = inc - cnt;
+            if (THREADS > 64 && np > 64) {               // (block-uniform) the pieces spill over the first wave
+                if (lane == 63) wsum[wave] = inc;
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w)
+                    if (w < wave) ex += wsum[w];
+            }
+            if (tid < np) {
+                psrc[tid] = src;
+                pdst[tid] = ex;
+            }
+            if (tid == 0) pdst[np] = nl;
         }
         __syncthreads();
         S1_DBG_MARK(0);
-        // expand the row's products into (tile col, product index) keys -- live ones only -- and sort them; equal
-        // tile columns stay in product (= ascending k) order because the index is part of the key
-        const int nl = row.expand_compact(tid, &s_cnt, THREADS, ordcnt);
+        for (int p = wave; p < np; p += WAVES) {         // the keys: (tile column, position in the row's list), list order
+            const unsigned s = psrc[p];
+            const int d0 = pdst[p], cnt = pdst[p + 1] - d0;
+            for (int t = lane; t < cnt; t += 64) keys[d0 + t] = (KeyT((unsigned)lj[s + (unsigned)t]) << QB) | KeyT(d0 + t);
+        }
+        if constexpr (THREADS < 1024) {                  // the register sorts load THREADS * 2^e >= nl keys: pad
+            int upto = THREADS;
+            while (upto < nl) upto <<= 1;
+            for (int x = nl + tid; x < upto; x += THREADS) keys[x] = ~KeyT(0);
+        }
+        __syncthreads();
         S1_DBG_MARK(1);
+        S1Row<KeyT, CAP, QB, THREADS> row;
+        row.keys = keys;
         if constexpr (THREADS == 1024) {
-            // 16-wave bins (more than 2048 live keys): the keys sit in product order, so a STABLE radix sort on the tile
+            // 16-wave bins (more than 2048 live keys): the keys sit in list order, so a STABLE radix sort on the tile
             // column bits alone (2 passes for up to 65536 tile columns) replaces a bitonic network over the whole key
             row.template sort_radix<EMAX>(tid, nl, radix_hist, wsum, QB, key_bits);
         } else if (nl <= THREADS)
@@ -847,79 +892,139 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
             row.template sort_regs<4, LOGT>(tid);
         else
             row.template sort_regs<8, LOGT>(tid);             // a bin never holds more than CAP = THREADS * EMAX live keys
-        // stream out the live products (the dead ones sorted behind them): sorted pairs, and per distinct tile
-        // column (C tile) its column + first pair; output positions count live products only
         S1_DBG_MARK(2);
-        const int lp0 = row_lbase[i], nlive = nl;
         int base = 0;
-        for (int s0 = 0; s0 < nlive; s0 += THREADS) {
+        for (int s0 = 0; s0 < nl; s0 += THREADS) {
             const int s = s0 + tid;
-            const bool valid = s < nlive;
-            int j = 0, a = 0, b = 0;
+            const bool valid = s < nl;
+            int j = 0;
+            int2 ab = make_int2(0, 0);
             bool head = false;
             if (valid) {
-                KeyT key = keys[s];
-                int q = (int)(key & KeyT((1u << QB) - 1u));
-                if constexpr (RANK) q = qmap[q];
+                const KeyT key = keys[s];
+                const int idx = (int)(key & KeyT((1u << QB) - 1u));
                 j = (int)(key >> QB);
                 head = s == 0 || (int)(keys[s - 1] >> QB) != j;
-                const auto pr = row.tile_b(q, false);
-                a = pr.a;
-                b = pr.b;
+                const int p = np == 1 ? 0 : s1_find_a(pdst, 0, np, idx);
+                ab = lab[psrc[p] + (unsigned)(idx - pdst[p])];
             }
-            unsigned long long bal = __ballot(head);
-            if (lane == 0) wsum[wave] = __popcll(bal);
-            __syncthreads();
-            int woff = 0, tot = 0;
+            const unsigned long long bal = __ballot(head);
+            int woff = 0, tot = __popcll(bal);
+            if constexpr (THREADS > 64) {
+                if (lane == 0) wsum[wave] = tot;
+                __syncthreads();
+                tot = 0;
 #pragma unroll
-            for (int w = 0; w < THREADS / 64; ++w) {
-                int c = wsum[w];
-                if (w < wave) woff += c;
-                tot += c;
+                for (int w = 0; w < WAVES; ++w) {
+                    const int c = wsum[w];
+                    if (w < wave) woff += c;
+                    tot += c;
+                }
             }
             if (valid) {
-                pairs_a[lp0 + s] = a;
-                pairs_b[lp0 + s] = b;
+                pairs_a[lp0 + s] = ab.x;
+                pairs_b[lp0 + s] = ab.y;
                 if (head) {
-                    int rank = base + woff + __popcll(bal & lt);
+                    const int rank = base + woff + __popcll(bal & lt);
                     scratch_col[lp0 + rank] = j;
                     scratch_off[lp0 + rank] = lp0 + s;
                 }
             }
             base += tot;
-            __syncthreads();
+            if constexpr (THREADS > 64) __syncthreads();
         }
         // the row's slots behind its last tile start no tile: marked, and holding the end of the row's pairs (step 2 reads
         // a tile's pair range as [scratch_off[slot], scratch_off[slot + 1]))
-        for (int x = base + tid; x < nlive; x += THREADS) {
+        for (int x = base + tid; x < nl; x += THREADS) {
             scratch_col[lp0 + x] = -1;
-            scratch_off[lp0 + x] = lp0 + nlive;
+            scratch_off[lp0 + x] = lp0 + nl;
         }
         // step 2 walks the slots in blocks of 256: note, for every block boundary inside this row's range, the row and
         // the boundary's position in the range (how many of the row's slots lie before it)
-        for (long long b = ((long long)lp0 + 255) / 256 + tid; b * 256 < (long long)lp0 + nlive; b += THREADS)   // (64-bit: lp0 + nlive reaches 2^31 - 1)
+        for (long long b = ((long long)lp0 + 255) / 256 + tid; b * 256 < (long long)lp0 + nl; b += THREADS)   // (64-bit: lp0 + nl reaches 2^31 - 1)
             block_info[b] = make_int2(i, (int)(b * 256 - lp0));
         if (tid == 0) row_tc[i] = base;
         S1_DBG_MARK(3);
 #ifdef PEM_S1_DEBUG
         if (tid == 0) {
-            if (blockIdx.x < 1024) {
-                unsigned hw, xcc;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                g_s1blk[DBG_BIN][blockIdx.x][0] = dbg_row0;
-                g_s1blk[DBG_BIN][blockIdx.x][1] = dbg_t;
-                g_s1blk[DBG_BIN][blockIdx.x][2] = hw;
-                g_s1blk[DBG_BIN][blockIdx.x][3] = xcc;
-            }
             atomicAdd(&g_s1dbg[DBG_BIN][blockIdx.x & 1023][4], 1ull);
             atomicMax(&g_s1dbg[DBG_BIN][blockIdx.x & 1023][5], dbg_t - dbg_row0);
         }
 #endif
+        __syncthreads();                                  // the tables are rebuilt by the next row
     }
 }
 
-// rows above the largest LDS bin: global expand (s1_xl_expand_kernel above) + radix sort + emit
+// Oversized rows (above the largest LDS bin, or more pieces than a bin's table holds): the row's pieces are copied into the
+// row's own stretch of the 64-bit key buffer -- key (tile column, slot) for the per-row sort, (row, tile column) for the global
+// one -- with the (A tile, B tile) of every product beside it; any number of pieces, 1024 per trip.
+__global__ void __launch_bounds__(1024) s1_xl_gather_kernel(const int *__restrict__ xl_rows, int nrows_xl, const int *__restrict__ xl_base,
+                                                            const int *__restrict__ a_tile_rowptr, int tr_lo, int a_lo,
+                                                            const int2 *__restrict__ aseg, const int *__restrict__ lj, const int2 *__restrict__ lab,
+                                                            int bits_tc, int local_keys, uint64_t *__restrict__ keys, uint32_t *__restrict__ perm,
+                                                            int *__restrict__ prod_a, int *__restrict__ prod_b)
+{
+    constexpr int WAVES = 16;
+    __shared__ unsigned psrc[1024];
+    __shared__ int pdst[1025];
+    __shared__ int wsum[WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int li = blockIdx.x; li < nrows_xl; li += gridDim.x) {
+        const int i = xl_rows[li];
+        const int ra0 = a_tile_rowptr[tr_lo + i] - a_lo, ra1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
+        const int c0 = ra0 / S1_CH, c1 = (ra1 - 1) / S1_CH;
+        int run = xl_base[i];                             // (block-uniform) next slot of the row's stretch
+        for (int pc0 = c0; pc0 <= c1; pc0 += 1024) {
+            const int nb = c1 - pc0 + 1 < 1024 ? c1 - pc0 + 1 : 1024;
+            unsigned src = 0;
+            int cnt = 0;
+            if (tid < nb) {
+                const int c = pc0 + tid;
+                const int first = ra0 > c * S1_CH ? ra0 : c * S1_CH, last = (ra1 < c * S1_CH + S1_CH ? ra1 : c * S1_CH + S1_CH) - 1;
+                const int2 s = aseg[first], e = aseg[last];
+                src = (unsigned)s.x;
+                cnt = (int)((unsigned)e.x + (unsigned)e.y - src);
+            }
+            int inc = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += o;
+            }
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            int ex = inc - cnt, tot = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                if (w < wave) ex += wsum[w];
+                tot += wsum[w];
+            }
+            if (tid < nb) {
+                psrc[tid] = src;
+                pdst[tid] = run + ex;
+            }
+            if (tid == 0) pdst[nb] = run + tot;
+            __syncthreads();
+            for (int p = wave; p < nb; p += WAVES) {
+                const unsigned s = psrc[p];
+                const int d0 = pdst[p], n = pdst[p + 1] - d0;
+                for (int t = lane; t < n; t += 64) {
+                    const int x = d0 + t;
+                    const unsigned col = (unsigned)lj[s + (unsigned)t];
+                    const int2 ab = lab[s + (unsigned)t];
+                    keys[x] = local_keys ? ((uint64_t)col << 32) | (uint64_t)(unsigned)x : ((uint64_t)(unsigned)i << bits_tc) | (uint64_t)col;
+                    perm[x] = (uint32_t)x;
+                    prod_a[x] = ab.x;
+                    prod_b[x] = ab.y;
+                }
+            }
+            run += tot;
+            __syncthreads();                              // the tables are rebuilt by the next trip
+        }
+    }
+}
+
+// oversized rows, global form: s1_xl_gather_kernel + radix sort on (row, tile column) + emit
 __global__ void s1_xl_rowstart_kernel(const uint64_t *__restrict__ keys, size_t n, int bits_tc, int *__restrict__ xl_rowstart)
 {
     size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -958,15 +1063,13 @@ __global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint3
     if (((p0 + s) & 255) == 0) block_info[(p0 + s) >> 8] = make_int2(i, s);   // block boundary of step 2 (see s1_rowsort_kernel)
     if (s == 0) row_tc[i] = ntiles_row;
 }
-
-// Oversized rows, one workgroup per row.  The global path above sorts all oversized rows' products together: four radix
-// passes over (row, tile column) keys, each a histogram launch, a scan and a scatter launch, then heads, a scan, row starts and
-// the emit -- nineteen launches for what is, on webbase-1M, forty tile rows of ~40 k products (its directory pages: a row of
-// 4 700 A tiles fits no LDS table): 0.3 ms of launch latency on the critical path of a 1.1 ms pass.  But s1_xl_expand_kernel
-// has already put every such row's live products into the row's OWN stretch of the key buffer, in product order.  So each row
-// is sorted where it lies by one 1024-thread workgroup: a stable LSD radix sort on the tile-column bits with the keys in
-// global memory (L2-resident: a row is a few hundred KB) -- per-wave digit histograms in LDS, one scan of the 16 x 256
-// counters, ballot-ranked scatter, as in the 16-wave LDS bins -- followed by the same emit as s1_rowsort_kernel.  One launch.
+// Oversized rows, one workgroup per row.  The global form sorts all oversized rows' products together: four radix passes over
+// (row, tile column) keys, each a histogram launch, a scan and a scatter launch, then heads, a scan, row starts and the emit --
+// nineteen launches.  But s1_xl_gather_kernel has put every such row's live products into the row's OWN stretch of the key
+// buffer, in list order.  So each row is sorted where it lies by one 1024-thread workgroup: a stable LSD radix sort on the
+// tile-column bits with the keys in global memory (L2-resident: a row is a few hundred KB) -- per-wave digit histograms in LDS,
+// one scan of the 16 x 256 counters, ballot-ranked scatter, as in the 16-wave LDS bins -- followed by the same emit as
+// s1_rowsort_kernel.  One launch.
 constexpr int S1_XLL_MAX = 1 << 18;     // rows with more live products than this keep the global path (one workgroup would take too long)
 __global__ void __launch_bounds__(1024) s1_xl_rowsort_kernel(const int *__restrict__ xl_rows, int nrows_xl, const int *__restrict__ xl_base,
                                                              const int *__restrict__ row_lbase, uint64_t *k0, uint64_t *k1, int bits_tc,
@@ -1120,7 +1223,6 @@ __global__ void __launch_bounds__(256) s1_crowidx_kernel(const int *__restrict__
     for (int i = wave; i < mt; i += nwaves)
         for (int t = c_rowptr[i] + lane; t < c_rowptr[i + 1]; t += 64) c_rowidx[t] = i + tr_lo;
 }
-
 static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
 {
     const pem_tiled *A = p->A, *B = p->B;
@@ -1139,8 +1241,7 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
     PEM_TRY(p->lprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
     if (nA > 0)
         PEM_LAUNCH(ctx, s1_aprod_kernel, grid_for((size_t)nA * 8, 256), 256, A->tile_colidx.as<int>(), A->tile_occ.as<uint32_t>(), p->a_lo, nA,
-                   B->tile_rowptr.as<int>(), B->tile_occ.as<uint32_t>(), prune, p->aprod_off.as<int>(), p->lprod_off.as<int>(),
-                   (const long long *)nullptr, 0, (int *)nullptr, (int *)nullptr);
+                   B->tile_rowptr.as<int>(), B->tile_occ.as<uint32_t>(), prune, p->aprod_off.as<int>(), p->lprod_off.as<int>());
     PEM_TRY(exclusive_scan_i32_pair(ctx, p->aprod_off.as<int>(), p->lprod_off.as<int>(), (size_t)nA, ctx->d_scalars + 3, ctx->d_scalars));
     int64_t P = 0, Pall = 0;
     {
@@ -1165,10 +1266,9 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->sk1.reserve(sizeof(uint64_t) * n));
         PEM_TRY(p->sv0.reserve(sizeof(uint32_t) * n));
         PEM_TRY(p->sv1.reserve(sizeof(uint32_t) * n));
-        PEM_LAUNCH(ctx, s1_xl_expand_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_keys.as<long long>(), A->tile_rowptr.as<int>(),
-                   A->tile_occ.as<uint32_t>(), p->a_lo, nA, p->tr_lo, p->lprod_off.as<int>(), (const int *)nullptr, B->tile_rowptr.as<int>(),
-                   B->tile_colidx.as<int>(), B->tile_occ.as<uint32_t>(), prune, bits_tc, p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(),
-                   p->prod_a.as<int>(), p->prod_b.as<int>(), 0, (const int *)nullptr);
+        PEM_LAUNCH(ctx, s1_esc_expand_kernel, grid_for((size_t)nA * 16, 256), 256, A->tile_keys.as<long long>(), A->tile_occ.as<uint32_t>(), p->a_lo,
+                   nA, p->tr_lo, p->lprod_off.as<int>(), B->tile_rowptr.as<int>(), B->tile_colidx.as<int>(), B->tile_occ.as<uint32_t>(), prune,
+                   bits_tc, p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(), p->prod_a.as<int>(), p->prod_b.as<int>());
         uint64_t *keys = nullptr;
         PEM_TRY(radix_sort_u64_u32(ctx, p->sk0.as<uint64_t>(), p->sk1.as<uint64_t>(), p->sv0.as<uint32_t>(), p->sv1.as<uint32_t>(), n,
                                    bits_tc + bits_row, &keys, &p->sorted_perm));
@@ -1195,33 +1295,30 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
     p->state = 1;
     return PEM_OK;
 }
-
-template <typename KeyT>
-static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int mt, int cap3, int prune, bool rank2)
+// the row bins, concurrently: the largest non-empty one on the main stream, the others forked onto auxiliary streams and
+// joined before the row-count scan.  Order matters: a block of the 32768-key bin needs a CU's whole LDS, so it can only start
+// on an EMPTY CU.  On the main stream it is dispatched the moment the row classification retires, a few microseconds before the
+// forked streams get through their event waits, and its blocks are placed before the smaller bins flood the CUs.
+static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int mt, int bits_tc, bool force64)
 {
-    const pem_tiled *A = p->A, *B = p->B;
+    const pem_tiled *A = p->A;
     int *rl = p->row_list.as<int>();
-    constexpr int QBITS = sizeof(KeyT) == 4 ? 15 : 24;   // product-index field of the sort key
-    const int key_bits = QBITS + bits_for((uint64_t)B->tile_cols);
-#define PEM_ROWSORT(BIN, CAP, QB, THREADS, RCAP, MAXGRID)                                                                                 \
-    if (counts[BIN] > 0) {                                                                                                           \
-        int grid = counts[BIN] < (MAXGRID) ? counts[BIN] : (MAXGRID);                                                                \
-        PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<" #CAP ">", (s1_rowsort_kernel<KeyT, CAP, QB, THREADS, RCAP>), grid, THREADS,             \
-                         rl + (size_t)(BIN) * mt, counts[BIN], A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, A->tile_colidx.as<int>(), \
-                         p->aprod_off.as<int>(), p->row_n.as<int>(), p->row_lbase.as<int>(), B->tile_rowptr.as<int>(),              \
-                         B->tile_colocc.as<int2>(), A->tile_occ.as<uint32_t>(), prune, p->pairs_a.as<int>(), p->pairs_b.as<int>(),     \
-                         p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->block_info.as<int2>(), p->c_tile_rowptr.as<int>(),     \
-                         key_bits);                                                                                                    \
-    }
-    // The bins are independent and run concurrently: the largest non-empty one on the main stream, the others
-    // forked onto auxiliary streams and joined before the row-count scan.  Order matters: a block of the 32768-key
-    // bin needs a CU's whole LDS, so it can only start on an EMPTY CU.  On the main stream it is dispatched the
-    // moment the row classification retires, a few microseconds before the forked streams get through their
-    // event waits, and its ~100 blocks are placed before the smaller bins flood the CUs (behind them it was
-    // starved until they drained, which made it the critical path of step 1).
+#define PEM_ROWSORT_ARGS(BIN, QB)                                                                                                        \
+    rl + (size_t)(BIN) * mt, counts[BIN], A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->aseg.as<int2>(), p->row_lbase.as<int>(),       \
+        p->live_j.as<int>(), p->live_ab.as<int2>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->scratch_col.as<int>(),                \
+        p->scratch_off.as<int>(), p->block_info.as<int2>(), p->c_tile_rowptr.as<int>(), (QB) + bits_tc
+#define PEM_ROWSORT(BIN, CAP, QB, THREADS)                                                                                               \
+    do {                                                                                                                                 \
+        if (bits_tc + (QB) <= 32 && !force64)                                                                                            \
+            PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<" #CAP ">", (s1_rowsort_kernel<uint32_t, CAP, QB, THREADS>), counts[BIN], THREADS,    \
+                             PEM_ROWSORT_ARGS(BIN, QB));                                                                                 \
+        else                                                                                                                             \
+            PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<" #CAP ",key64>", (s1_rowsort_kernel<uint64_t, CAP, QB, THREADS>), counts[BIN],      \
+                             THREADS, PEM_ROWSORT_ARGS(BIN, QB));                                                                        \
+    } while (0)
     hipStream_t main_stream = ctx->stream;
     (void)hipEventRecord(ctx->ev_fork, main_stream);
-    bool forked[3] = {false, false, false};
+    bool forked[4] = {false, false, false, false};
     int next_aux = -1;                     // -1: the main stream is still free
     const bool serial = p->opt_s1_serial != 0;   // diagnostic: every bin alone, one after the other
     auto bin_begin = [&]() {
@@ -1236,42 +1333,37 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
         ctx->stream = main_stream;
         ++next_aux;
     };
-    if constexpr (sizeof(KeyT) == 4) {
-        if (cap3 > S1_CAP2 && counts[3] > 0) {
-            bin_begin();
-            PEM_ROWSORT(3, 32768, QBITS, 1024, 1024, 1 << 20)
-            bin_end();
-        }
+    if (counts[4] > 0) {                   // (only populated where 32-bit keys hold a 15-bit index: see the row classification's cap4)
+        bin_begin();
+        PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<32768>", (s1_rowsort_kernel<uint32_t, S1_CAP4, S1_QB4, 1024>), counts[4], 1024,
+                         PEM_ROWSORT_ARGS(4, S1_QB4));
+        bin_end();
+    }
+    if (counts[3] > 0) {
+        bin_begin();
+        PEM_ROWSORT(3, 8192, S1_QB3, 1024);
+        bin_end();
     }
     if (counts[2] > 0) {
         bin_begin();
-        if (rank2) {
-            // B with 2^17 .. 2^19 tile columns (cage15: 322 179): the 8192-key bin sorts 32-bit (tile column, live position)
-            // keys -- 78 KB of LDS, two workgroups per CU -- instead of 64-bit (tile column, product index) keys at 106 KB
-            const int grid = counts[2];
-            PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<8192,rank>", (s1_rowsort_kernel<uint32_t, 8192, 13, 1024, 1024, true>), grid, 1024,
-                             rl + (size_t)2 * mt, counts[2], A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, A->tile_colidx.as<int>(),
-                             p->aprod_off.as<int>(), p->row_n.as<int>(), p->row_lbase.as<int>(), B->tile_rowptr.as<int>(),
-                             B->tile_colocc.as<int2>(), A->tile_occ.as<uint32_t>(), prune, p->pairs_a.as<int>(), p->pairs_b.as<int>(),
-                             p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->block_info.as<int2>(), p->c_tile_rowptr.as<int>(),
-                             13 + bits_for((uint64_t)B->tile_cols));
-        } else {
-            PEM_ROWSORT(2, 8192, QBITS, 1024, 2048, 1 << 20)
-        }
+        PEM_ROWSORT(2, 2048, S1_QB2, 256);
         bin_end();
     }
     if (counts[1] > 0) {
         bin_begin();
-        PEM_ROWSORT(1, 2048, QBITS, 256, 1024, 1 << 20)
+        PEM_ROWSORT(1, 512, S1_QB1, 64);
         bin_end();
     }
     if (counts[0] > 0) {
         bin_begin();
-        PEM_ROWSORT(0, 512, QBITS, 64, 256, 1 << 20)
+        PEM_LAUNCH(ctx, s1_tiny_kernel, grid_for((size_t)counts[0] * 64, 256), 256, rl, counts[0], p->row_desc.as<int4>(), p->row_lbase.as<int>(),
+                   p->live_j.as<int>(), p->live_ab.as<int2>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->scratch_col.as<int>(),
+                   p->scratch_off.as<int>(), p->block_info.as<int2>(), p->c_tile_rowptr.as<int>());
         bin_end();
     }
 #undef PEM_ROWSORT
-    for (int k = 0; k < 3; ++k)
+#undef PEM_ROWSORT_ARGS
+    for (int k = 0; k < 4; ++k)
         if (forked[k]) (void)hipStreamWaitEvent(main_stream, ctx->ev_join[k], 0);
 }
 
@@ -1280,24 +1372,14 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     const pem_tiled *A = p->A, *B = p->B;
     hipStream_t st = ctx->stream;
     const int nA = p->a_hi - p->a_lo, mt = p->tr_hi - p->tr_lo;
+    const int nchunks = (nA + S1_CH - 1) / S1_CH;
     const int bits_tc = bits_for((uint64_t)B->tile_cols), bits_row = bits_for((uint64_t)(mt > 0 ? mt : 1));
-    // the 32768-key LDS bin needs 32-bit keys (tile col + 15 index bits); wider B goes to the global path above 8192
-    // 32-bit keys = tile col + 15 index bits; wider B uses 64-bit keys (24 index bits, no 32768-key LDS bin)
-    // (a row of exactly 2^15 products in a B of exactly 2^17 tile columns could form the key 0xFFFFFFFF, which is the
-    // padding key: the index field holds 2^15 - 1 products at most)
-    const bool k32 = bits_tc + 15 <= 32 && !p->opt_key64;
-    const int cap3 = k32 ? S1_CAP3 : S1_CAP2;
-    const int qcap = k32 ? (1 << 15) - 1 : (1 << 24) - 1;
-    const int xlcap = p->opt_xlcap > 0 ? p->opt_xlcap : 0x7FFFFFFF;   // test hook: rows with more live products take the global path
-    // the two small bins also bound a row's products BEFORE pruning: they are all expanded, 64 (256) per trip, and a row of 300
-    // live products among 20 000 kept its one wave busy for 60 us -- the whole kernel's time on a 1/8 row block of webbase-1M.
-    // Eight times the live capacity: at twice, the 8-way shares gained most (0.283 -> 0.270 ms on average) but the band matrices,
-    // whose rows all carry 3-4 dead products per live one, moved up a bin wholesale (cage15 step 1 20.4 -> 23.9 ms)
-    const int ncap0 = S1_NCAP0, ncap1 = S1_NCAP1;
-    // 2^17 < tile columns < 2^19: the 8192-key bin takes 32-bit (tile column, live position) keys (see launch_rowsorts); its
-    // product index lives in a 16-bit side table and its A-tile table is the smaller one
-    const bool rank2 = !k32 && !p->opt_key64 && B->tile_cols < (1 << 19);
-    const int rcap2 = rank2 ? 1024 : S1_RCAP2, qcap2 = rank2 ? 65535 : qcap;
+    // 32-bit keys = tile column + the bin's index bits (6 .. 15); where they do not fit (B with more than 2^17 tile columns in the
+    // 32768-key bin, 2^19 in the 8192-key one, ...) the bin sorts 64-bit keys, and the 32768-key bin -- 256 KB of them -- is left out
+    const bool force64 = p->opt_key64 != 0;
+    const int tiny_ok = bits_tc + S1_QB0 <= 32 && !force64;
+    const int cap4 = (bits_tc + S1_QB4 <= 32 && !force64) ? S1_CAP4 : 0;
+    const int xlcap = p->opt_xlcap > 0 ? p->opt_xlcap : 0x7FFFFFFF;   // test hook: rows with more live products take the oversized-row path
     p->state = 0;
     p->pairs_ready = false;
     p->c_rowidx_valid = false;
@@ -1305,15 +1387,38 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     p->ntiles_c = p->npairs = p->nnz_c = 0;
     if (!ctx->capturing) PEM_HIP(hipEventRecord(ctx->ev[0], st));
     PEM_TRY(p->c_tile_rowptr.reserve(sizeof(int) * ((size_t)mt + 4)));
-    PEM_TRY(p->row_list.reserve(sizeof(int) * (5 * (size_t)mt + 4)));
-    PEM_TRY(p->bin_count.reserve(sizeof(int) * 8));
+    PEM_TRY(p->row_list.reserve(sizeof(int) * (S1_NLIST * (size_t)mt + 4)));
+    PEM_TRY(p->bin_count.reserve(sizeof(int) * BC_INTS));
     PEM_TRY(p->xl_base.reserve(sizeof(int) * ((size_t)mt + 4)));
     PEM_TRY(p->pairs_offset.reserve(sizeof(int) * 4));
-    // one launch clears the status flags, the bin counters, the pass scalars (P live, T_C, C_nnz, P all), pairs_offset[0]
-    // and the per-row product totals; the per-row tile counts in c_tile_rowptr are zeroed by the row classification below
-    PEM_TRY(p->row_n.reserve(sizeof(int) * ((size_t)mt + 4)));
     PEM_TRY(p->row_lbase.reserve(sizeof(int) * ((size_t)mt + 4)));
-    // (a repeat pass knows T_C, so the reset also clears step 2's group counters and saves it a memset)
+    PEM_TRY(p->row_desc.reserve(sizeof(int4) * ((size_t)mt + 1)));
+    PEM_TRY(p->aseg.reserve(sizeof(int2) * ((size_t)nA + 4)));
+    PEM_TRY(p->chunk_seg.reserve(sizeof(int2) * ((size_t)nchunks + 1)));
+    PEM_TRY(p->chunk_n.reserve(sizeof(long long) * ((size_t)nchunks + 1)));
+    // The live list holds one slot per tile-level product of the slice (a wave of the expansion takes its chunk's slots before
+    // it has tested anything, see s1_expand_kernel); how many that is is counted on the first pass of a plan.  That pass also
+    // arms the list's allocator; every later one finds it re-armed by the row classification of the pass before.
+    if (!p->warm_pass) {
+        PEM_HIP(hipMemsetAsync(p->bin_count.as<int>() + BC_FAULT, 0, sizeof(int) * (BC_INTS - BC_FAULT), st));
+        PEM_HIP(hipMemsetAsync(ctx->d_scalars + 8, 0, sizeof(int64_t), st));
+        if (nA > 0)
+            PEM_LAUNCH(ctx, s1_total_kernel, grid_for((size_t)nA, 256), 256, A->tile_colidx.as<int>(), p->a_lo, nA, B->tile_rowptr.as<int>(),
+                       reinterpret_cast<unsigned long long *>(ctx->d_scalars + 8));
+        int64_t ntotal = 0;
+        PEM_TRY(read_scalars(ctx, ctx->d_scalars + 8, 1, &ntotal));
+        if (ntotal >= 0xFFFFFFFFll - 64) {
+            set_error("step 1: %lld tile-level products in this row block exceed the 32-bit positions of the live-product list; split the rows "
+                      "(pem_split_tile_rows) or use PEM_OPT_STEP1_GLOBAL_SORT", (long long)ntotal);
+            return PEM_E_OVERFLOW;
+        }
+        p->w_ntotal = ntotal;
+    }
+    const size_t ncap = (size_t)p->w_ntotal;
+    PEM_TRY(arena_phase(ctx->arena, {{&p->live_j, sizeof(int) * (ncap + 64)}, {&p->live_ab, sizeof(int2) * (ncap + 64)}}));
+    PEM_TRY(p->live_j.reserve(sizeof(int) * (ncap + 64)));
+    PEM_TRY(p->live_ab.reserve(sizeof(int2) * (ncap + 64)));
+    // (a repeat pass knows T_C, so the row classification also clears step 2's group counters and saves it a memset)
     int ngroups_reset = 0;
     p->group_nnz_cleared = false;
     if (p->warm_pass && p->w_TC > 0) {
@@ -1321,38 +1426,31 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->group_nnz.reserve(sizeof(int) * (size_t)ngroups_reset));
         p->group_nnz_cleared = true;
     }
-    const size_t reset_n = std::max((size_t)mt + 1, (size_t)ngroups_reset);
-    PEM_LAUNCH(ctx, s1_reset_kernel, grid_for(reset_n, 256), 256, ctx->d_flags, p->bin_count.as<int>(),
-               reinterpret_cast<long long *>(ctx->d_scalars), p->pairs_offset.as<int>(), p->c_tile_rowptr.as<int>(), mt, p->row_n.as<int>(),
-               p->row_lbase.as<int>(), p->group_nnz.as<int>(), ngroups_reset);
-    // products per A tile (all: expansion; live: what is sorted and stored) and their totals per tile row.  The only scan
-    // left is the one over the ROWS' live totals (row r's pairs, and its C tile slots, start at row_lbase[r]); offsets inside
-    // a row are rebuilt in LDS by the row's workgroup, and the grand total of all products is only ever a 64-bit scalar --
-    // so a product whose tile-level products exceed 2^31 (cage15 on one GPU: 2.8 G) is fine as long as the LIVE pairs,
-    // which the reference's int arrays index, do not.
     const int prune = p->opt_prune;
-    PEM_TRY(p->aprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
-    PEM_TRY(p->lprod_off.reserve(sizeof(int) * ((size_t)nA + 4)));
-    if (nA > 0)
-        PEM_LAUNCH(ctx, s1_aprod_kernel, grid_for((size_t)nA * 8, 256), 256, A->tile_colidx.as<int>(), A->tile_occ.as<uint32_t>(), p->a_lo, nA,
-                   B->tile_rowptr.as<int>(), B->tile_occ.as<uint32_t>(), prune, p->aprod_off.as<int>(), p->lprod_off.as<int>(),
-                   A->tile_keys.as<long long>(), p->tr_lo, p->row_n.as<int>(), p->row_lbase.as<int>());
+    PEM_LAUNCH(ctx, s1_expand_kernel, (unsigned)(nchunks > 0 ? nchunks : 1), 64 * S1_XW, A->tile_colidx.as<int>(), A->tile_occ.as<uint32_t>(),
+               p->a_lo, nA, B->tile_rowptr.as<int>(), B->tile_colocc.as<int2>(), prune, p->bin_count.as<int>(), (unsigned long long)ncap,
+               p->aseg.as<int2>(), p->chunk_seg.as<int2>(), p->chunk_n.as<long long>(), p->live_j.as<int>(), p->live_ab.as<int2>(), ctx->d_flags,
+               reinterpret_cast<long long *>(ctx->d_scalars));
+    // per-row tile counts are accumulated in c_tile_rowptr and scanned in place afterwards; the rows' live totals go to row_lbase and
+    // are scanned in place (row r's pairs, and its C tile slots, start at row_lbase[r])
+    {
+        const size_t span = std::max(std::max((size_t)mt, (size_t)nchunks), (size_t)1);
+        PEM_LAUNCH(ctx, s1_rowclass_kernel, grid_for(span, 256), 256, A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, mt, nchunks, p->aseg.as<int2>(),
+                   p->chunk_seg.as<int2>(), p->chunk_n.as<long long>(), tiny_ok, cap4, xlcap, p->row_lbase.as<int>(), p->row_desc.as<int4>(),
+                   p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(), p->c_tile_rowptr.as<int>(),
+                   reinterpret_cast<long long *>(ctx->d_scalars), ctx->d_flags, p->pairs_offset.as<int>(), p->group_nnz.as<int>(), ngroups_reset);
+    }
     PEM_TRY(exclusive_scan_i32(ctx, p->row_lbase.as<int>(), p->row_lbase.as<int>(), (size_t)mt, ctx->d_scalars));
-    // per-row tile counts are accumulated in c_tile_rowptr and scanned in place afterwards
-    if (mt > 0)
-        PEM_LAUNCH(ctx, s1_rowclass_kernel, grid_for((size_t)mt, 256), 256, A->tile_rowptr.as<int>(), p->tr_lo, mt, p->row_n.as<int>(),
-                   p->row_lbase.as<int>(), cap3, qcap, xlcap, rcap2, qcap2, ncap0, ncap1, p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(),
-                   p->c_tile_rowptr.as<int>(), reinterpret_cast<long long *>(ctx->d_scalars));
     // one read-back: P, the bin populations and the product total of the oversized rows
     int64_t P = 0, Pall = 0;
-    int counts[4];
+    int counts[5];
     size_t n_xl;
     int nrows_xl = 0, max_xl = 0;
     if (p->warm_pass) {
         max_xl = p->w_max_xl;
         P = p->w_P;
         Pall = p->w_Pall;
-        for (int b = 0; b < 4; ++b) counts[b] = p->w_counts[b];
+        for (int b = 0; b < 5; ++b) counts[b] = p->w_counts[b];
         n_xl = (size_t)p->w_nxl;
         nrows_xl = p->w_nrows_xl;
     } else {
@@ -1362,10 +1460,10 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(read_scalars(ctx, ctx->d_scalars, 4, sc));
         P = sc[0];
         Pall = sc[3];
-        for (int b = 0; b < 4; ++b) counts[b] = p->w_counts[b] = hb[b];
-        n_xl = (size_t)hb[5];
-        nrows_xl = p->w_nrows_xl = hb[4];
-        max_xl = p->w_max_xl = hb[6];
+        for (int b = 0; b < 5; ++b) counts[b] = p->w_counts[b] = hb[b];
+        nrows_xl = p->w_nrows_xl = hb[BC_XL_ROWS];
+        n_xl = (size_t)hb[BC_XL_TOTAL];
+        max_xl = p->w_max_xl = hb[BC_XL_MAX];
         p->w_nxl = (int64_t)n_xl;
         p->w_P = P;
         p->w_Pall = Pall;
@@ -1388,10 +1486,9 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->scratch_col.reserve(sizeof(int) * (n + 4)));
         PEM_TRY(p->scratch_off.reserve(sizeof(int) * (n + 4)));
         PEM_TRY(p->block_info.reserve(sizeof(int2) * (n / 256 + 4)));
-        // Oversized rows.  Up to S1_XLL_MAX live products each they are sorted where they lie, one workgroup per row: three
-        // launches with no shared scratch, so the chain runs on a stream of its own BESIDE the row bins (it is a third of the
-        // bins' time on webbase-1M; behind them it was a quarter of the whole pass).  Larger ones go through the global sort,
-        // after the bins (it uses the context's scan and sort scratch).
+        // Oversized rows.  Up to S1_XLL_MAX live products each they are sorted where they lie, one workgroup per row: two
+        // launches with no shared scratch, so the chain runs on a stream of its own BESIDE the row bins.  Larger ones go through
+        // the global sort, after the bins (it uses the context's scan and sort scratch).
         const bool xl_local = n_xl > 0 && !p->opt_xl_global && max_xl <= S1_XLL_MAX;
         if (n_xl > 0) {
             PEM_TRY(p->prod_a.reserve(sizeof(int) * n_xl));
@@ -1401,38 +1498,30 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
             PEM_TRY(p->sv0.reserve(sizeof(uint32_t) * n_xl));
             PEM_TRY(p->sv1.reserve(sizeof(uint32_t) * n_xl));
             PEM_TRY(p->xl_rowstart.reserve(sizeof(int) * ((size_t)mt + 4)));
-            PEM_TRY(p->xl_lrel.reserve(sizeof(int) * ((size_t)nA + 4)));
         }
-        auto xl_expand = [&](int local) {
-            PEM_LAUNCH(ctx, s1_xl_rel_kernel, (unsigned)(nrows_xl > 0 ? nrows_xl : 1), 1024, p->row_list.as<int>() + (size_t)4 * mt, nrows_xl,
-                       A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->lprod_off.as<int>(), p->xl_lrel.as<int>());
-            // (the grid: the oversized rows x sixteen A tiles per block up to the plan's longest tile row)
-            const dim3 xgrid((unsigned)((p->max_row_tiles + 15) / 16 > 0 ? (p->max_row_tiles + 15) / 16 : 1), (unsigned)(nrows_xl > 0 ? nrows_xl : 1));
-            PEM_LAUNCH(ctx, s1_xl_expand_kernel, xgrid, 256, A->tile_keys.as<long long>(), A->tile_rowptr.as<int>(),
-                       A->tile_occ.as<uint32_t>(), p->a_lo, nA, p->tr_lo, p->xl_lrel.as<int>(), p->xl_base.as<int>(), B->tile_rowptr.as<int>(),
-                       B->tile_colidx.as<int>(), B->tile_occ.as<uint32_t>(), prune, bits_tc, p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(),
-                       p->prod_a.as<int>(), p->prod_b.as<int>(), local, p->row_list.as<int>() + (size_t)4 * mt);
+        const int *xl_rows = p->row_list.as<int>() + (size_t)5 * mt;
+        auto xl_gather = [&](int local) {
+            PEM_LAUNCH(ctx, s1_xl_gather_kernel, (unsigned)(nrows_xl > 0 ? nrows_xl : 1), 1024, xl_rows, nrows_xl, p->xl_base.as<int>(),
+                       A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->aseg.as<int2>(), p->live_j.as<int>(), p->live_ab.as<int2>(), bits_tc, local,
+                       p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(), p->prod_a.as<int>(), p->prod_b.as<int>());
         };
         if (xl_local) {
             hipStream_t main_stream = ctx->stream;
             (void)hipEventRecord(ctx->ev_fork, main_stream);
-            (void)hipStreamWaitEvent(ctx->aux[3], ctx->ev_fork, 0);
-            ctx->stream = ctx->aux[3];
-            xl_expand(1);
-            PEM_LAUNCH(ctx, s1_xl_rowsort_kernel, (unsigned)(nrows_xl > 0 ? nrows_xl : 1), 1024, p->row_list.as<int>() + (size_t)4 * mt, nrows_xl,
-                       p->xl_base.as<int>(), p->row_lbase.as<int>(), p->sk0.as<uint64_t>(), p->sk1.as<uint64_t>(), bits_tc, p->prod_a.as<int>(),
-                       p->prod_b.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(),
-                       p->block_info.as<int2>(), p->c_tile_rowptr.as<int>());
-            (void)hipEventRecord(ctx->ev_join[3], ctx->aux[3]);
+            (void)hipStreamWaitEvent(ctx->aux[4], ctx->ev_fork, 0);
+            ctx->stream = ctx->aux[4];
+            xl_gather(1);
+            PEM_LAUNCH(ctx, s1_xl_rowsort_kernel, (unsigned)(nrows_xl > 0 ? nrows_xl : 1), 1024, xl_rows, nrows_xl, p->xl_base.as<int>(),
+                       p->row_lbase.as<int>(), p->sk0.as<uint64_t>(), p->sk1.as<uint64_t>(), bits_tc, p->prod_a.as<int>(), p->prod_b.as<int>(),
+                       p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->block_info.as<int2>(),
+                       p->c_tile_rowptr.as<int>());
+            (void)hipEventRecord(ctx->ev_join[4], ctx->aux[4]);
             ctx->stream = main_stream;
         }
-        if (k32)
-            launch_rowsorts<uint32_t>(ctx, p, counts, mt, cap3, prune, false);
-        else
-            launch_rowsorts<uint64_t>(ctx, p, counts, mt, cap3, prune, rank2);
-        if (xl_local) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join[3], 0);
-        if (n_xl > 0 && !xl_local) {   // global expand + stable radix sort on (row, tile col)
-            xl_expand(0);
+        launch_rowsorts(ctx, p, counts, mt, bits_tc, force64);
+        if (xl_local) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join[4], 0);
+        if (n_xl > 0 && !xl_local) {   // stable radix sort on (row, tile col) over all oversized rows together
+            xl_gather(0);
             uint64_t *keys = nullptr;
             uint32_t *perm = nullptr;
             PEM_TRY(radix_sort_u64_u32(ctx, p->sk0.as<uint64_t>(), p->sk1.as<uint64_t>(), p->sv0.as<uint32_t>(), p->sv1.as<uint32_t>(), n_xl,
@@ -1464,6 +1553,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     p->state = 1;
     return PEM_OK;
 }
+
 
 // row-local scratch -> _C_tileColIdx / pair offsets (reference layout) without step 2: the step-wise API after step 1,
 // and the 16-lanes-per-tile baseline kernels

@@ -7,7 +7,7 @@ if os.path.isdir(src):
     src = sorted(glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True))[0]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r["Queue_Id"]) for r in csv.DictReader(open(src)))
-first = [i for i, k in enumerate(ks) if k[2].startswith("s1_reset")]
+first = [i for i, k in enumerate(ks) if k[2].startswith("s1_expand")]
 i0, i1 = first[which], first[which + 1] if which + 1 < len(first) else len(ks)
 t0 = ks[i0][0]
 print(f"# pass {which} of {len(first)} in {os.path.basename(src)}; times in us from the pass's first kernel")
