@@ -200,8 +200,8 @@ struct pem_ctx {
     // timing
     hipEvent_t ev[8] = {};             // step spans
     // fork/join inside a step: an independent long-tailed kernel runs on an auxiliary stream
-    hipStream_t aux[5] = {};           // [0..3]: step 1's row bins; [4]: its oversized-row chain
-    hipEvent_t ev_fork = nullptr, ev_join[5] = {};
+    hipStream_t aux[3] = {};           // step 1's row bins and its oversized-row chain: with the main stream, the runtime's four hardware queues
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {};
     pem_timings timings = {};
     bool profiling = false;
     std::vector<pem::KernelStat> stats;

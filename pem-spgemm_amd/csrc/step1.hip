@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(64 * S1_XW) s1_expand_kernel(const int *__rest
     static_assert(S1_CH == 64 * S1_XW, "one thread per A tile of the chunk");
     __shared__ unsigned t_end[S1_CH];                 // A tile a's products are [t_end[a - 1], t_end[a]) of the chunk's sequence
     __shared__ uint2 t_pay[S1_CH];                    // (d, occupied columns of A tile a): B tile of product q of A tile a = q + d
-    __shared__ unsigned t_hist[S1_XW][64];            // per wave: how many A tiles end at each product of the trip in hand
+    __shared__ unsigned t_hist[S1_XW][64 * S1_XU];    // per wave: how many A tiles end at each product of the iteration in hand
     __shared__ unsigned long long t_bal[S1_XTRIPS];   // per trip of the epoch: its live products
     __shared__ unsigned t_cum[S1_XTRIPS + 1];         // ... and the chunk's live products before it (S1_SENT: not known yet)
     __shared__ unsigned s_wsum[S1_XW];
@@ -288,44 +288,41 @@ __global__ void __launch_bounds__(64 * S1_XW) s1_expand_kernel(const int *__rest
 #ifdef PEM_S1_DEBUG
             const unsigned long long dt0 = wall_clock64();
 #endif
-            // the A tile holding product qb0: the first whose products end beyond it (wave-uniform search over the table)
-            int a = 0;
-#pragma unroll
-            for (int step = S1_CH / 2; step > 0; step >>= 1)
-                if (t_end[a + step - 1] <= qb0) a += step;
-            a = __builtin_amdgcn_readfirstlane(a);
-            // The A tile of every product of a trip, without a search: the tile of product q is a + #{tiles a' >= a whose products end at or
-            // before q}.  The lanes, as A TILES a + lane, drop a count at the position their products end (if inside the trip); the lanes, as
-            // PRODUCTS, read the counts back and prefix-sum them (six DPP steps).  Five LDS operations and ~25 vector instructions per
-            // trip however many A tiles it spans (a six-step shuffle search per product made the LDS crossbar the kernel's bound, a
-            // scalar walk over the tiles its instruction issue: 18 instructions per A tile and trip).
-            int bb[S1_XU], aa[S1_XU];
-            unsigned ac[S1_XU];
+            // the A tile holding product qb0 = the number of A tiles whose products end at or before it: two ballots over the table
+            // (every eighth entry, then the eight entries of the group) instead of a nine-step search
+            int a0;
+            {
+                const int c8 = __popcll(__ballot(t_end[8 * lane + 7] <= qb0));
+                const int g = c8 < 64 ? c8 : 63;
+                a0 = 8 * g + __popcll(__ballot(lane < 8 && t_end[8 * g + (lane & 7)] <= qb0));
+            }
+            // The A tile of every product of the iteration, without a search per product: the tile of product q is
+            // a0 + #{tiles a' >= a0 whose products end at or before q}.  The lanes, as A TILES a0 + lane, drop a count at the position
+            // their products end (if inside the iteration's 256); the lanes, as PRODUCTS, read the counts back and prefix-sum them
+            // (six DPP steps per trip).  A dozen LDS operations and ~60 vector instructions per iteration however many A tiles it
+            // spans (a six-step shuffle search per product made the LDS crossbar the kernel's bound, a scalar walk over the tiles
+            // its instruction issue: 18 instructions per A tile and trip).
             volatile unsigned *hist = t_hist[wave];
 #pragma unroll
+            for (int u = 0; u < S1_XU; ++u) hist[64 * u + lane] = 0;
+            for (int aw = a0; aw < S1_CH; aw += 64) {            // (one window of 64 tiles, unless more than 64 end inside these 256 products: empty B rows)
+                const unsigned ve = aw + lane < S1_CH ? t_end[aw + lane] : 0xFFFFFFFFu;
+                const unsigned m = ve - qb0;                     // (tiles from a0 on end beyond qb0: m >= 1)
+                const bool inside = m < 64u * S1_XU;
+                if (inside) __hip_atomic_fetch_add(const_cast<unsigned *>(&hist[m]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (__popcll(__ballot(inside)) < 64) break;
+            }
+            int bb[S1_XU], aa[S1_XU];
+            unsigned ac[S1_XU];
+            int before_trip = a0;                                // tiles ending at or before the trip's first product (+ a0)
+#pragma unroll
             for (int u = 0; u < S1_XU; ++u) {
-                const unsigned qb = qb0 + 64u * (unsigned)u, q = qb + (unsigned)lane;
-                bb[u] = 0;
-                aa[u] = 0;
-                ac[u] = 0;
-                if (qb >= N_run) continue;                       // (wave-uniform)
-                int ta = 0;                                      // tiles ending at or before my product, over the windows walked
-                for (;;) {
-                    hist[lane] = 0;
-                    const unsigned ve = a + lane < S1_CH ? t_end[a + lane] : 0xFFFFFFFFu;
-                    const unsigned m = ve - qb;                  // (tiles before the cursor end at or before qb: none is in the window)
-                    if (m < 64u) __hip_atomic_fetch_add(&hist[m], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    const int incl = s1_wave_inclusive_scan_dpp((int)hist[lane]);
-                    ta += incl;
-                    const int done = __builtin_amdgcn_readlane(incl, 63);
-                    a += done;
-                    if (done < 64 || a >= S1_CH) break;          // (64: every tile of the window ended inside the trip -- empty B rows; next window)
-                }
-                // (ta counts the tiles that END at or before q: my tile is the next one.  The cursor for the next trip is already there.)
-                const int mine = (a - __builtin_amdgcn_readlane(ta, 63)) + ta;
-                aa[u] = mine < S1_CH ? mine : S1_CH - 1;
+                const int incl = s1_wave_inclusive_scan_dpp((int)hist[64 * u + lane]);
+                const int mine = before_trip + incl;
+                before_trip += __builtin_amdgcn_readlane(incl, 63);
+                aa[u] = mine < S1_CH ? mine : S1_CH - 1;         // (products past the chunk's end: any tile)
                 const uint2 pay = t_pay[aa[u]];
-                bb[u] = (int)q + (int)pay.x;
+                bb[u] = (int)(qb0 + 64u * (unsigned)u + (unsigned)lane) + (int)pay.x;
                 ac[u] = pay.y;
             }
 #ifdef PEM_S1_DEBUG
@@ -818,6 +815,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
     __shared__ unsigned psrc[THREADS];   // piece p of the row: where it lies in the live list ...
     __shared__ int pdst[THREADS + 1];    // ... and where it goes in the row's list (exclusive scan of the piece lengths)
     __shared__ int wsum[WAVES];
+    __shared__ int segcnt[CAP / 64];     // C tiles per 64 sorted keys, then their exclusive scan (emit)
     __shared__ unsigned radix_hist[THREADS == 1024 ? WAVES * 256 : 1];   // digit counters of the radix sort (16-wave bins)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -866,10 +864,23 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
         }
         __syncthreads();
         S1_DBG_MARK(0);
-        for (int p = wave; p < np; p += WAVES) {         // the keys: (tile column, position in the row's list), list order
-            const unsigned s = psrc[p];
-            const int d0 = pdst[p], cnt = pdst[p + 1] - d0;
-            for (int t = lane; t < cnt; t += 64) keys[d0 + t] = (KeyT((unsigned)lj[s + (unsigned)t]) << QB) | KeyT(d0 + t);
+        // the keys: (tile column, position in the row's list), list order.  Every thread takes positions of the list, finds their
+        // piece (a short search over the table; most rows have one piece) and loads from the live list: all the row's loads are
+        // independent (a wave per piece walked a 1 200-key piece of a directory row in nineteen dependent trips)
+        for (int x0 = tid; x0 < nl; x0 += 4 * THREADS) {
+            unsigned src[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int x = x0 + u * THREADS < nl ? x0 + u * THREADS : nl - 1;
+                const int p = np == 1 ? 0 : s1_find_a(pdst, 0, np, x);
+                src[u] = psrc[p] + (unsigned)(x - pdst[p]);
+            }
+            int jj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) jj[u] = lj[src[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (x0 + u * THREADS < nl) keys[x0 + u * THREADS] = (KeyT((unsigned)jj[u]) << QB) | KeyT(x0 + u * THREADS);
         }
         if constexpr (THREADS < 1024) {                  // the register sorts load THREADS * 2^e >= nl keys: pad
             int upto = THREADS;
@@ -893,9 +904,45 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
         else
             row.template sort_regs<8, LOGT>(tid);             // a bin never holds more than CAP = THREADS * EMAX live keys
         S1_DBG_MARK(2);
-        int base = 0;
-        for (int s0 = 0; s0 < nl; s0 += THREADS) {
-            const int s = s0 + tid;
+        // Emit, in two sweeps over the sorted keys in segments of 64 (one wave each, round robin).  First the C tiles (distinct tile
+        // columns) of every segment are counted and the counts scanned; then every segment knows where its tiles go and the
+        // second sweep -- the gathers of the pairs' (A tile, B tile) and all the stores -- runs without a barrier, its loads in
+        // flight together (one sweep with two barriers per 1 024 keys took 15 us for a directory row's eleven trips).
+        const int nseg = (nl + 63) >> 6;
+        for (int g = wave; g < nseg; g += WAVES) {
+            const int s = 64 * g + lane;
+            const bool head = s < nl && (s == 0 || (int)(keys[s - 1] >> QB) != (int)(keys[s] >> QB));
+            const unsigned long long bal = __ballot(head);
+            if (lane == 0) segcnt[g] = __popcll(bal);
+        }
+        __syncthreads();
+        int base = 0;                                     // the row's C tiles
+        {
+            const int v = tid < nseg ? segcnt[tid] : 0;   // (nseg <= CAP / 64 <= THREADS)
+            int inc = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += o;
+            }
+            int ex = inc - v;
+            if constexpr (THREADS > 64) {
+                if (lane == 63) wsum[wave] = inc;
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w) {
+                    if (w < wave) ex += wsum[w];
+                    base += wsum[w];
+                }
+            } else {
+                base = __shfl(inc, 63, 64);
+            }
+            if (tid < nseg) segcnt[tid] = ex;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int g = wave; g < nseg; g += WAVES) {
+            const int s = 64 * g + lane;
             const bool valid = s < nl;
             int j = 0;
             int2 ab = make_int2(0, 0);
@@ -909,29 +956,15 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
                 ab = lab[psrc[p] + (unsigned)(idx - pdst[p])];
             }
             const unsigned long long bal = __ballot(head);
-            int woff = 0, tot = __popcll(bal);
-            if constexpr (THREADS > 64) {
-                if (lane == 0) wsum[wave] = tot;
-                __syncthreads();
-                tot = 0;
-#pragma unroll
-                for (int w = 0; w < WAVES; ++w) {
-                    const int c = wsum[w];
-                    if (w < wave) woff += c;
-                    tot += c;
-                }
-            }
             if (valid) {
                 pairs_a[lp0 + s] = ab.x;
                 pairs_b[lp0 + s] = ab.y;
                 if (head) {
-                    const int rank = base + woff + __popcll(bal & lt);
+                    const int rank = segcnt[g] + __popcll(bal & lt);
                     scratch_col[lp0 + rank] = j;
                     scratch_off[lp0 + rank] = lp0 + s;
                 }
             }
-            base += tot;
-            if constexpr (THREADS > 64) __syncthreads();
         }
         // the row's slots behind its last tile start no tile: marked, and holding the end of the row's pairs (step 2 reads
         // a tile's pair range as [scratch_off[slot], scratch_off[slot + 1]))
@@ -1295,11 +1328,41 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
     p->state = 1;
     return PEM_OK;
 }
-// the row bins, concurrently: the largest non-empty one on the main stream, the others forked onto auxiliary streams and
-// joined before the row-count scan.  Order matters: a block of the 32768-key bin needs a CU's whole LDS, so it can only start
-// on an EMPTY CU.  On the main stream it is dispatched the moment the row classification retires, a few microseconds before the
-// forked streams get through their event waits, and its blocks are placed before the smaller bins flood the CUs.
-static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int mt, int bits_tc, bool force64)
+// The row bins and the oversized-row chain run concurrently on FOUR streams -- the main one and three auxiliary ones, forked
+// behind the row classification and joined before the row-count scan.  Four, because the runtime feeds four hardware queues: a
+// fifth stream shares a queue with one of the others, and in round 4's first cut the one-key-per-lane kernel (62 k waves, the
+// bulk of the work) landed behind the 32768-key bin (five workgroups, 61 us) on the main stream's queue.  The plan, by what
+// each kernel takes alone on webbase-1M:   main: tiny rows (25 us), then the 512-key bin (21)   aux 0: 32768-key bin (61)
+//                                          aux 1: 8192-key bin (35)                              aux 2: 2048-key bin (28), then the oversized rows
+struct S1Lanes {
+    pem_ctx *ctx;
+    hipStream_t main_stream;
+    bool serial, forked[3] = {false, false, false};
+    S1Lanes(pem_ctx *c, bool serial_) : ctx(c), main_stream(c->stream), serial(serial_) { (void)hipEventRecord(c->ev_fork, c->stream); }
+    void on(int lane)                      // 0: main stream; 1..3: auxiliary stream lane - 1
+    {
+        if (lane == 0 || serial) {
+            ctx->stream = main_stream;
+            return;
+        }
+        if (!forked[lane - 1]) {
+            (void)hipStreamWaitEvent(ctx->aux[lane - 1], ctx->ev_fork, 0);
+            forked[lane - 1] = true;
+        }
+        ctx->stream = ctx->aux[lane - 1];
+    }
+    void join()
+    {
+        ctx->stream = main_stream;
+        for (int k = 0; k < 3; ++k)
+            if (forked[k]) {
+                (void)hipEventRecord(ctx->ev_join[k], ctx->aux[k]);
+                (void)hipStreamWaitEvent(main_stream, ctx->ev_join[k], 0);
+            }
+    }
+};
+
+static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const int *counts, int mt, int bits_tc, bool force64)
 {
     const pem_tiled *A = p->A;
     int *rl = p->row_list.as<int>();
@@ -1316,55 +1379,32 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, const int *counts, int m
             PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<" #CAP ",key64>", (s1_rowsort_kernel<uint64_t, CAP, QB, THREADS>), counts[BIN],      \
                              THREADS, PEM_ROWSORT_ARGS(BIN, QB));                                                                        \
     } while (0)
-    hipStream_t main_stream = ctx->stream;
-    (void)hipEventRecord(ctx->ev_fork, main_stream);
-    bool forked[4] = {false, false, false, false};
-    int next_aux = -1;                     // -1: the main stream is still free
-    const bool serial = p->opt_s1_serial != 0;   // diagnostic: every bin alone, one after the other
-    auto bin_begin = [&]() {
-        if (next_aux < 0 || serial) return;
-        (void)hipStreamWaitEvent(ctx->aux[next_aux], ctx->ev_fork, 0);
-        ctx->stream = ctx->aux[next_aux];
-        forked[next_aux] = true;
-    };
-    auto bin_end = [&]() {
-        if (serial) return;
-        if (next_aux >= 0) (void)hipEventRecord(ctx->ev_join[next_aux], ctx->aux[next_aux]);
-        ctx->stream = main_stream;
-        ++next_aux;
-    };
     if (counts[4] > 0) {                   // (only populated where 32-bit keys hold a 15-bit index: see the row classification's cap4)
-        bin_begin();
+        lanes.on(1);
         PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<32768>", (s1_rowsort_kernel<uint32_t, S1_CAP4, S1_QB4, 1024>), counts[4], 1024,
                          PEM_ROWSORT_ARGS(4, S1_QB4));
-        bin_end();
     }
     if (counts[3] > 0) {
-        bin_begin();
+        lanes.on(2);
         PEM_ROWSORT(3, 8192, S1_QB3, 1024);
-        bin_end();
     }
     if (counts[2] > 0) {
-        bin_begin();
+        lanes.on(3);
         PEM_ROWSORT(2, 2048, S1_QB2, 256);
-        bin_end();
-    }
-    if (counts[1] > 0) {
-        bin_begin();
-        PEM_ROWSORT(1, 512, S1_QB1, 64);
-        bin_end();
     }
     if (counts[0] > 0) {
-        bin_begin();
+        lanes.on(0);
         PEM_LAUNCH(ctx, s1_tiny_kernel, grid_for((size_t)counts[0] * 64, 256), 256, rl, counts[0], p->row_desc.as<int4>(), p->row_lbase.as<int>(),
                    p->live_j.as<int>(), p->live_ab.as<int2>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->scratch_col.as<int>(),
                    p->scratch_off.as<int>(), p->block_info.as<int2>(), p->c_tile_rowptr.as<int>());
-        bin_end();
     }
+    if (counts[1] > 0) {
+        lanes.on(0);
+        PEM_ROWSORT(1, 512, S1_QB1, 64);
+    }
+    lanes.on(0);
 #undef PEM_ROWSORT
 #undef PEM_ROWSORT_ARGS
-    for (int k = 0; k < 4; ++k)
-        if (forked[k]) (void)hipStreamWaitEvent(main_stream, ctx->ev_join[k], 0);
 }
 
 static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
@@ -1505,21 +1545,17 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
                        A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->aseg.as<int2>(), p->live_j.as<int>(), p->live_ab.as<int2>(), bits_tc, local,
                        p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(), p->prod_a.as<int>(), p->prod_b.as<int>());
         };
+        S1Lanes lanes(ctx, p->opt_s1_serial != 0);
+        launch_rowsorts(ctx, p, lanes, counts, mt, bits_tc, force64);
         if (xl_local) {
-            hipStream_t main_stream = ctx->stream;
-            (void)hipEventRecord(ctx->ev_fork, main_stream);
-            (void)hipStreamWaitEvent(ctx->aux[4], ctx->ev_fork, 0);
-            ctx->stream = ctx->aux[4];
+            lanes.on(3);
             xl_gather(1);
             PEM_LAUNCH(ctx, s1_xl_rowsort_kernel, (unsigned)(nrows_xl > 0 ? nrows_xl : 1), 1024, xl_rows, nrows_xl, p->xl_base.as<int>(),
                        p->row_lbase.as<int>(), p->sk0.as<uint64_t>(), p->sk1.as<uint64_t>(), bits_tc, p->prod_a.as<int>(), p->prod_b.as<int>(),
                        p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->block_info.as<int2>(),
                        p->c_tile_rowptr.as<int>());
-            (void)hipEventRecord(ctx->ev_join[4], ctx->aux[4]);
-            ctx->stream = main_stream;
         }
-        launch_rowsorts(ctx, p, counts, mt, bits_tc, force64);
-        if (xl_local) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_join[4], 0);
+        lanes.join();
         if (n_xl > 0 && !xl_local) {   // stable radix sort on (row, tile col) over all oversized rows together
             xl_gather(0);
             uint64_t *keys = nullptr;

@@ -26,7 +26,7 @@ ms = {}
 for k, v in ctx.kernel_stats().items():
     if "rowsort" in k:
         ms[int(k.split("<")[1].split(">")[0].split(",")[0])] = v["total_ms"] / v["calls"]
-names = ["stage", "expand", "sort", "emit"]
+names = ["pieces", "load", "sort", "emit"]
 for b, cap in enumerate([512, 2048, 8192, 32768]):
     v = [buf[b * 8 + k] for k in range(8)]
     rows = max(v[4], 1)
