@@ -328,14 +328,15 @@ struct pem_cplan {
     pem::DevBuf sk0, sk1, sv0, sv1;    // sort buffers
     uint32_t *sorted_perm = nullptr;   // points into sv0/sv1
     // row-local step 1
-    pem::DevBuf row_list, bin_count, xl_base, xl_rowstart, scratch_col, scratch_off;
+    pem::DevBuf row_list, bin_count, xl_base, xl_rowstart;
+    pem::DevBuf pair_col;              // int per live pair (final order): tile column of its C tile, sign bit set on the first pair of every C tile
+    pem::DevBuf blk_heads;             // int per 256 pairs: first pairs (C tiles) among them, then (scanned) C tiles in front of them
     bool pairs_ready = false;          // step 1 already wrote pairs_a / pairs_b
     bool flags_mirrored = false;       // ... and left the pass's status flags in ctx->h_flags
     bool verify_folded = false;        // this pass's size check ran inside s2_entries_kernel
     bool group_nnz_cleared = false;    // step 1's reset already zeroed group_nnz for this pass
     bool wide = true;                  // step 2 ran the fused kernel (step 3 then runs entry-per-lane); false: 16-lanes-per-tile baseline
     bool compact_valid = false;        // c_tile_colidx / pairs_offset hold the dense layout (else: row-local scratch, see ensure_compact)
-    pem::DevBuf block_info;            // int2 per 256-slot block of the step-1 scratch: (tile row of the block's first slot, its position in the row's range)
     pem::DevBuf group_nnz;             // C entries per S2_GROUP tiles (s2_tiles_kernel -> scan -> s2_entries_kernel)
     // sizes of the last complete pass on this plan.  A and B are immutable, so a repeat pass has the same
     // sizes: it skips the three host read-backs and a device-side check compares them at the end instead.

@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
                                                           int *__restrict__ row_l, int4 *__restrict__ row_desc, int *__restrict__ row_list,
                                                           int *__restrict__ bin_count, int *__restrict__ xl_base, int *__restrict__ row_tc,
                                                           long long *__restrict__ scalars, int *__restrict__ flags, int *__restrict__ pairs_offset,
-                                                          int *__restrict__ group_nnz, int ngroups)
+                                                          int *__restrict__ group_nnz, int ngroups, int *__restrict__ blk_heads, int nblk)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -507,6 +507,7 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
         atomicMax(&bin_count[BC_XL_MAX], nl);
     }
     for (int g = i; g < ngroups; g += gridDim.x * blockDim.x) group_nnz[g] = 0;   // step 2's entry counts per S2_GROUP tiles (repeat passes: size known)
+    for (int g = i; g < nblk; g += gridDim.x * blockDim.x) blk_heads[g] = 0;      // first pairs per 256 pairs, counted by the row sorts (repeat passes: size known)
     if (i == 0) {
         pairs_offset[0] = 0;
         row_tc[mt] = 0;
@@ -605,11 +606,24 @@ __device__ __forceinline__ void s1_bitonic_regs(KeyT (&v)[EPT], KeyT *lds, const
 // carry the end of the row's pairs), the row's tile count, and for every 256-slot boundary inside the row's range the pair
 // (row, position) -- block_info, which is what lets step 2 index C tiles densely without scanning the slots.
 // ------------------------------------------------------------------------------------------
+// first pairs (C tiles) per 256 pairs of the stream, for step 2's dense tile index: 64 consecutive pairs starting at pair p0,
+// `bal` = which of them are first pairs; they lie in at most two blocks of 256
+__device__ __forceinline__ void s1_note_heads(int *__restrict__ blk_heads, const long long p0, const unsigned long long bal)
+{
+    if (!bal) return;
+    const long long b0 = p0 >> 8;
+    const int k = (int)(((b0 + 1) << 8) - p0);                   // pairs of the 64 that lie in block b0 (>= 1)
+    const unsigned long long m0 = k >= 64 ? ~0ull : (1ull << k) - 1ull;
+    const int c0 = __popcll(bal & m0), c1 = __popcll(bal & ~m0);
+    if (c0) atomicAdd(&blk_heads[b0], c0);
+    if (c1) atomicAdd(&blk_heads[b0 + 1], c1);
+}
+
 // rows of at most 64 live products in at most two pieces: one wave, one key per lane, everything in registers
 __global__ void __launch_bounds__(256) s1_tiny_kernel(const int *__restrict__ row_list, int nrows_bin, const int4 *__restrict__ row_desc,
                                                       const int *__restrict__ row_lbase, const int *__restrict__ lj, const int2 *__restrict__ lab,
-                                                      int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ scratch_col,
-                                                      int *__restrict__ scratch_off, int2 *__restrict__ block_info, int *__restrict__ row_tc)
+                                                      int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ pair_col,
+                                                      int *__restrict__ blk_heads, int *__restrict__ row_tc)
 {
     const int lane = threadIdx.x & 63;
     const int li = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -640,24 +654,14 @@ __global__ void __launch_bounds__(256) s1_tiny_kernel(const int *__restrict__ ro
     const int jprev = __shfl_up(j, 1, 64);
     const bool head = valid && (lane == 0 || jprev != j);        // (sorted: the nl live keys are the first nl lanes)
     const unsigned long long bal = __ballot(head);
-    const int tiles = __popcll(bal);
     if (valid) {
         pairs_a[lp0 + lane] = a;
         pairs_b[lp0 + lane] = b;
-        if (head) {
-            const int rank = __popcll(bal & ((1ull << lane) - 1ull));
-            scratch_col[lp0 + rank] = j;
-            scratch_off[lp0 + rank] = lp0 + lane;
-        }
-        if (lane >= tiles) {                                     // the row's slots behind its last tile start no tile
-            scratch_col[lp0 + lane] = -1;
-            scratch_off[lp0 + lane] = lp0 + nl;
-        }
+        pair_col[lp0 + lane] = j | (head ? (int)0x80000000 : 0);
     }
     if (lane == 0) {
-        const long long bb = ((long long)lp0 + 255) / 256;       // at most one block boundary of step 2 falls inside 64 slots
-        if (bb * 256 < (long long)lp0 + nl) block_info[bb] = make_int2(i, (int)(bb * 256 - lp0));
-        row_tc[i] = tiles;
+        s1_note_heads(blk_heads, lp0, bal);
+        row_tc[i] = __popcll(bal);
     }
 }
 
@@ -804,8 +808,8 @@ template <typename KeyT, int CAP, int QB, int THREADS>
 __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || sizeof(KeyT) == 8 ? 4 : 8) : 1)
     s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr, int tr_lo, int a_lo,
                       const int2 *__restrict__ aseg, const int *__restrict__ row_lbase, const int *__restrict__ lj, const int2 *__restrict__ lab,
-                      int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ scratch_col, int *__restrict__ scratch_off,
-                      int2 *__restrict__ block_info, int *__restrict__ row_tc, int key_bits)
+                      int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ pair_col, int *__restrict__ blk_heads,
+                      int *__restrict__ row_tc, int key_bits)
 {
     constexpr int LOGT = THREADS == 64 ? 6 : THREADS == 256 ? 8 : 10;
     constexpr int EMAX = CAP / THREADS, WAVES = THREADS / 64;
@@ -815,10 +819,9 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
     __shared__ unsigned psrc[THREADS];   // piece p of the row: where it lies in the live list ...
     __shared__ int pdst[THREADS + 1];    // ... and where it goes in the row's list (exclusive scan of the piece lengths)
     __shared__ int wsum[WAVES];
-    __shared__ int segcnt[CAP / 64];     // C tiles per 64 sorted keys, then their exclusive scan (emit)
     __shared__ unsigned radix_hist[THREADS == 1024 ? WAVES * 256 : 1];   // digit counters of the radix sort (16-wave bins)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long lt = (1ull << lane) - 1ull;
+    (void)0;
 #ifdef PEM_S1_DEBUG
     constexpr int DBG_BIN = CAP == 512 ? 0 : CAP == 2048 ? 1 : CAP == 8192 ? 2 : 3;
     unsigned long long dbg_t = 0;
@@ -904,42 +907,11 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
         else
             row.template sort_regs<8, LOGT>(tid);             // a bin never holds more than CAP = THREADS * EMAX live keys
         S1_DBG_MARK(2);
-        // Emit, in two sweeps over the sorted keys in segments of 64 (one wave each, round robin).  First the C tiles (distinct tile
-        // columns) of every segment are counted and the counts scanned; then every segment knows where its tiles go and the
-        // second sweep -- the gathers of the pairs' (A tile, B tile) and all the stores -- runs without a barrier, its loads in
-        // flight together (one sweep with two barriers per 1 024 keys took 15 us for a directory row's eleven trips).
+        // Emit: one sweep over the sorted keys in segments of 64 (one wave each, round robin), no barrier -- the gathers of the
+        // pairs' (A tile, B tile) are in flight together.  A pair that opens a C tile (a new tile column) carries the mark in
+        // pair_col's sign bit; the marks per 256 pairs of the stream are counted for step 2's dense tile index.
         const int nseg = (nl + 63) >> 6;
-        for (int g = wave; g < nseg; g += WAVES) {
-            const int s = 64 * g + lane;
-            const bool head = s < nl && (s == 0 || (int)(keys[s - 1] >> QB) != (int)(keys[s] >> QB));
-            const unsigned long long bal = __ballot(head);
-            if (lane == 0) segcnt[g] = __popcll(bal);
-        }
-        __syncthreads();
-        int base = 0;                                     // the row's C tiles
-        {
-            const int v = tid < nseg ? segcnt[tid] : 0;   // (nseg <= CAP / 64 <= THREADS)
-            int inc = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_up(inc, d, 64);
-                if (lane >= d) inc += o;
-            }
-            int ex = inc - v;
-            if constexpr (THREADS > 64) {
-                if (lane == 63) wsum[wave] = inc;
-                __syncthreads();
-#pragma unroll
-                for (int w = 0; w < WAVES; ++w) {
-                    if (w < wave) ex += wsum[w];
-                    base += wsum[w];
-                }
-            } else {
-                base = __shfl(inc, 63, 64);
-            }
-            if (tid < nseg) segcnt[tid] = ex;
-        }
-        __syncthreads();
+        int mytiles = 0;
 #pragma unroll 2
         for (int g = wave; g < nseg; g += WAVES) {
             const int s = 64 * g + lane;
@@ -959,23 +931,22 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
             if (valid) {
                 pairs_a[lp0 + s] = ab.x;
                 pairs_b[lp0 + s] = ab.y;
-                if (head) {
-                    const int rank = segcnt[g] + __popcll(bal & lt);
-                    scratch_col[lp0 + rank] = j;
-                    scratch_off[lp0 + rank] = lp0 + s;
-                }
+                pair_col[lp0 + s] = j | (head ? (int)0x80000000 : 0);
+            }
+            if (lane == 0) {
+                s1_note_heads(blk_heads, (long long)lp0 + 64 * g, bal);
+                mytiles += __popcll(bal);
             }
         }
-        // the row's slots behind its last tile start no tile: marked, and holding the end of the row's pairs (step 2 reads
-        // a tile's pair range as [scratch_off[slot], scratch_off[slot + 1]))
-        for (int x = base + tid; x < nl; x += THREADS) {
-            scratch_col[lp0 + x] = -1;
-            scratch_off[lp0 + x] = lp0 + nl;
+        // the row's C tiles
+        int base = mytiles;
+        if constexpr (THREADS > 64) {
+            if (lane == 0) wsum[wave] = mytiles;
+            __syncthreads();
+            base = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) base += wsum[w];
         }
-        // step 2 walks the slots in blocks of 256: note, for every block boundary inside this row's range, the row and
-        // the boundary's position in the range (how many of the row's slots lie before it)
-        for (long long b = ((long long)lp0 + 255) / 256 + tid; b * 256 < (long long)lp0 + nl; b += THREADS)   // (64-bit: lp0 + nl reaches 2^31 - 1)
-            block_info[b] = make_int2(i, (int)(b * 256 - lp0));
         if (tid == 0) row_tc[i] = base;
         S1_DBG_MARK(3);
 #ifdef PEM_S1_DEBUG
@@ -1069,8 +1040,8 @@ __global__ void s1_xl_rowstart_kernel(const uint64_t *__restrict__ keys, size_t 
 __global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ perm, const int *__restrict__ headx, size_t n,
                                   int bits_tc, const int *__restrict__ xl_rowstart, const int *__restrict__ row_lbase,
                                   const int *__restrict__ prod_a, const int *__restrict__ prod_b,
-                                  int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ scratch_col,
-                                  int *__restrict__ scratch_off, int2 *__restrict__ block_info, int *__restrict__ row_tc)
+                                  int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ pair_col, int *__restrict__ blk_heads,
+                                  int *__restrict__ row_tc)
 {
     size_t x = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= n) return;
@@ -1078,24 +1049,16 @@ __global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint3
     int i = (int)(key >> bits_tc), j = (int)(key & ((1ull << bits_tc) - 1ull));
     int rs = xl_rowstart[i];
     int s = (int)x - rs;
-    int p0 = row_lbase[i], ni = row_lbase[i + 1] - p0;     // the row's live-product (= slot) range
+    int p0 = row_lbase[i], ni = row_lbase[i + 1] - p0;     // the row's live-product range
     uint32_t o = perm[x];
     pairs_a[p0 + s] = prod_a[o];
     pairs_b[p0 + s] = prod_b[o];
-    int hx = headx[x];
-    const int ntiles_row = headx[rs + ni] - headx[rs];
-    if (headx[x + 1] != hx) {
-        int rank = hx - headx[rs];
-        scratch_col[p0 + rank] = j;
-        scratch_off[p0 + rank] = p0 + s;
-    }
-    if (s >= ntiles_row) {   // slots behind the row's last tile (see s1_rowsort_kernel)
-        scratch_col[p0 + s] = -1;
-        scratch_off[p0 + s] = p0 + ni;
-    }
-    if (((p0 + s) & 255) == 0) block_info[(p0 + s) >> 8] = make_int2(i, s);   // block boundary of step 2 (see s1_rowsort_kernel)
-    if (s == 0) row_tc[i] = ntiles_row;
+    const bool head = headx[x + 1] != headx[x];            // (heads mark the FIRST key of every (row, tile column) run: see s1_heads_kernel)
+    pair_col[p0 + s] = j | (head ? (int)0x80000000 : 0);
+    if (head) atomicAdd(&blk_heads[(p0 + s) >> 8], 1);
+    if (s == 0) row_tc[i] = headx[rs + ni] - headx[rs];
 }
+
 // Oversized rows, one workgroup per row.  The global form sorts all oversized rows' products together: four radix passes over
 // (row, tile column) keys, each a histogram launch, a scan and a scatter launch, then heads, a scan, row starts and the emit --
 // nineteen launches.  But s1_xl_gather_kernel has put every such row's live products into the row's OWN stretch of the key
@@ -1107,8 +1070,8 @@ constexpr int S1_XLL_MAX = 1 << 18;     // rows with more live products than thi
 __global__ void __launch_bounds__(1024) s1_xl_rowsort_kernel(const int *__restrict__ xl_rows, int nrows_xl, const int *__restrict__ xl_base,
                                                              const int *__restrict__ row_lbase, uint64_t *k0, uint64_t *k1, int bits_tc,
                                                              const int *__restrict__ prod_a, const int *__restrict__ prod_b,
-                                                             int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ scratch_col,
-                                                             int *__restrict__ scratch_off, int2 *__restrict__ block_info, int *__restrict__ row_tc)
+                                                             int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ pair_col,
+                                                             int *__restrict__ blk_heads, int *__restrict__ row_tc)
 {
     constexpr int WAVES = 16;
     __shared__ unsigned hist[WAVES * 256];
@@ -1178,10 +1141,10 @@ __global__ void __launch_bounds__(1024) s1_xl_rowsort_kernel(const int *__restri
             src = dst;
             dst = t;
         }
-        // emit (as s1_rowsort_kernel): sorted pairs, and per distinct tile column its column + first pair into the row's slots
-        int tiles = 0;
-        for (int s0 = 0; s0 < n; s0 += 1024) {
-            const int sidx = s0 + tid;
+        // emit (as s1_rowsort_kernel): sorted pairs, the first pair of every C tile marked
+        int mytiles = 0;
+        for (int s0 = 64 * wave; s0 < n; s0 += 1024) {
+            const int sidx = s0 + lane;
             const bool valid = sidx < n;
             int j = 0, a = 0, b = 0;
             bool head = false;
@@ -1194,57 +1157,51 @@ __global__ void __launch_bounds__(1024) s1_xl_rowsort_kernel(const int *__restri
                 b = prod_b[x];
             }
             const unsigned long long bal = __ballot(head);
-            if (lane == 0) wsum[wave] = __popcll(bal);
-            __syncthreads();
-            int woff = 0, tot = 0;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) {
-                const int c = wsum[w];
-                if (w < wave) woff += c;
-                tot += c;
-            }
             if (valid) {
                 pairs_a[lp0 + sidx] = a;
                 pairs_b[lp0 + sidx] = b;
-                if (head) {
-                    const int rank = tiles + woff + __popcll(bal & lt);
-                    scratch_col[lp0 + rank] = j;
-                    scratch_off[lp0 + rank] = lp0 + sidx;
-                }
+                pair_col[lp0 + sidx] = j | (head ? (int)0x80000000 : 0);
             }
-            tiles += tot;
-            __syncthreads();
+            if (lane == 0) {
+                s1_note_heads(blk_heads, (long long)lp0 + s0, bal);
+                mytiles += __popcll(bal);
+            }
         }
-        for (int x = tiles + tid; x < n; x += 1024) {               // the row's slots behind its last tile (see s1_rowsort_kernel)
-            scratch_col[lp0 + x] = -1;
-            scratch_off[lp0 + x] = lp0 + n;
+        if (lane == 0) wsum[wave] = mytiles;
+        __syncthreads();
+        if (tid == 0) {
+            int tiles = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) tiles += wsum[w];
+            row_tc[i] = tiles;
         }
-        for (long long bb = ((long long)lp0 + 255) / 256 + tid; bb * 256 < (long long)lp0 + n; bb += 1024)
-            block_info[bb] = make_int2(i, (int)(bb * 256 - lp0));
-        if (tid == 0) row_tc[i] = tiles;
         __syncthreads();
     }
 }
 
-// row-local scratch -> reference layout (_C_tileColIdx, spgemm.cu:379; pair offsets :484)
-// One block per tile row: the row knows where its tiles go (c_rowptr[i]) and where its scratch lives (its first
-// pair), so the copy is two coalesced streams and needs no search.  (One WAVE per row was as fast on a whole matrix,
-// where the kernel is bandwidth-bound, but left a 1/8 slice -- 8 k rows of ~300 tiles -- latency-bound: 34 us.)
-__global__ void __launch_bounds__(256) s1_compact_kernel(const int *__restrict__ c_rowptr, int mt, long long ntc,
-                                                         const int *__restrict__ row_lbase,
-                                                         const int *__restrict__ scratch_col, const int *__restrict__ scratch_off, int npairs,
-                                                         int *__restrict__ c_colidx, int *__restrict__ pairs_offset)
+// pair stream -> reference layout (_C_tileColIdx, spgemm.cu:379; pair offsets :484) without step 2: the step-wise API after
+// step 1, and the 16-lanes-per-tile baseline kernels.  One workgroup per 256 pairs: a tile's dense index is the scanned count of
+// first pairs in front of the block + those in front of it inside the block.
+__global__ void __launch_bounds__(256) s1_compact_kernel(const int *__restrict__ pair_col, long long npairs, const int *__restrict__ blk_base,
+                                                         long long ntc, int *__restrict__ c_colidx, int *__restrict__ pairs_offset)
 {
-    for (int i = blockIdx.x; i < mt; i += gridDim.x) {
-        const int t0 = c_rowptr[i], cnt = c_rowptr[i + 1] - t0;
-        if (cnt == 0) continue;
-        const int p0 = row_lbase[i];
-        for (int r = threadIdx.x; r < cnt; r += blockDim.x) {
-            c_colidx[t0 + r] = scratch_col[p0 + r];
-            pairs_offset[t0 + r] = scratch_off[p0 + r];
-        }
+    __shared__ int wcnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int col = p < npairs ? pair_col[p] : 0;
+    const bool head = col < 0;
+    const unsigned long long bal = __ballot(head);
+    if (lane == 0) wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    long long t = (long long)blk_base[blockIdx.x] + __popcll(bal & ((1ull << lane) - 1ull));
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (w < wave) t += wcnt[w];
+    if (head) {
+        c_colidx[t] = col & 0x7FFFFFFF;
+        pairs_offset[t] = (int)p;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) pairs_offset[ntc] = npairs;
+    if (blockIdx.x == 0 && threadIdx.x == 0) pairs_offset[ntc] = (int)npairs;
 }
 
 // _C_tileRowIdx (spgemm.cu:378) from _C_rowPtr, one wave per tile row.  Like Ctiles_rowPtr it has no reader on the
@@ -1368,8 +1325,8 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
     int *rl = p->row_list.as<int>();
 #define PEM_ROWSORT_ARGS(BIN, QB)                                                                                                        \
     rl + (size_t)(BIN) * mt, counts[BIN], A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->aseg.as<int2>(), p->row_lbase.as<int>(),       \
-        p->live_j.as<int>(), p->live_ab.as<int2>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->scratch_col.as<int>(),                \
-        p->scratch_off.as<int>(), p->block_info.as<int2>(), p->c_tile_rowptr.as<int>(), (QB) + bits_tc
+        p->live_j.as<int>(), p->live_ab.as<int2>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->pair_col.as<int>(),                   \
+        p->blk_heads.as<int>(), p->c_tile_rowptr.as<int>(), (QB) + bits_tc
 #define PEM_ROWSORT(BIN, CAP, QB, THREADS)                                                                                               \
     do {                                                                                                                                 \
         if (bits_tc + (QB) <= 32 && !force64)                                                                                            \
@@ -1395,8 +1352,8 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
     if (counts[0] > 0) {
         lanes.on(0);
         PEM_LAUNCH(ctx, s1_tiny_kernel, grid_for((size_t)counts[0] * 64, 256), 256, rl, counts[0], p->row_desc.as<int4>(), p->row_lbase.as<int>(),
-                   p->live_j.as<int>(), p->live_ab.as<int2>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->scratch_col.as<int>(),
-                   p->scratch_off.as<int>(), p->block_info.as<int2>(), p->c_tile_rowptr.as<int>());
+                   p->live_j.as<int>(), p->live_ab.as<int2>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->pair_col.as<int>(),
+                   p->blk_heads.as<int>(), p->c_tile_rowptr.as<int>());
     }
     if (counts[1] > 0) {
         lanes.on(0);
@@ -1466,6 +1423,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->group_nnz.reserve(sizeof(int) * (size_t)ngroups_reset));
         p->group_nnz_cleared = true;
     }
+    const int nblk_reset = p->warm_pass ? (int)(p->w_P / 256 + 1) : 0;   // (the buffer is in place since the plan's first pass)
     const int prune = p->opt_prune;
     PEM_LAUNCH(ctx, s1_expand_kernel, (unsigned)(nchunks > 0 ? nchunks : 1), 64 * S1_XW, A->tile_colidx.as<int>(), A->tile_occ.as<uint32_t>(),
                p->a_lo, nA, B->tile_rowptr.as<int>(), B->tile_colocc.as<int2>(), prune, p->bin_count.as<int>(), (unsigned long long)ncap,
@@ -1478,7 +1436,8 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_LAUNCH(ctx, s1_rowclass_kernel, grid_for(span, 256), 256, A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, mt, nchunks, p->aseg.as<int2>(),
                    p->chunk_seg.as<int2>(), p->chunk_n.as<long long>(), tiny_ok, cap4, xlcap, p->row_lbase.as<int>(), p->row_desc.as<int4>(),
                    p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(), p->c_tile_rowptr.as<int>(),
-                   reinterpret_cast<long long *>(ctx->d_scalars), ctx->d_flags, p->pairs_offset.as<int>(), p->group_nnz.as<int>(), ngroups_reset);
+                   reinterpret_cast<long long *>(ctx->d_scalars), ctx->d_flags, p->pairs_offset.as<int>(), p->group_nnz.as<int>(), ngroups_reset,
+                   p->blk_heads.as<int>(), nblk_reset);
     }
     PEM_TRY(exclusive_scan_i32(ctx, p->row_lbase.as<int>(), p->row_lbase.as<int>(), (size_t)mt, ctx->d_scalars));
     // one read-back: P, the bin populations and the product total of the oversized rows
@@ -1518,14 +1477,15 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
     int64_t TC = 0;
     if (n > 0) {
         // sizing phase "pairs": everything P-sized comes out of one driver allocation (a repeat pass finds it all in place)
+        const size_t nblk = n / 256 + 1;
         PEM_TRY(arena_phase(ctx->arena, {{&p->pairs_a, sizeof(int) * (n + 4)}, {&p->pairs_b, sizeof(int) * (n + 4)},
-                                         {&p->scratch_col, sizeof(int) * (n + 4)}, {&p->scratch_off, sizeof(int) * (n + 4)},
-                                         {&p->block_info, sizeof(int2) * (n / 256 + 4)}}));
+                                         {&p->pair_col, sizeof(int) * (n + 4)}, {&p->blk_heads, sizeof(int) * (nblk + 4)}}));
         PEM_TRY(p->pairs_a.reserve(sizeof(int) * (n + 4)));
         PEM_TRY(p->pairs_b.reserve(sizeof(int) * (n + 4)));
-        PEM_TRY(p->scratch_col.reserve(sizeof(int) * (n + 4)));
-        PEM_TRY(p->scratch_off.reserve(sizeof(int) * (n + 4)));
-        PEM_TRY(p->block_info.reserve(sizeof(int2) * (n / 256 + 4)));
+        PEM_TRY(p->pair_col.reserve(sizeof(int) * (n + 4)));
+        PEM_TRY(p->blk_heads.reserve(sizeof(int) * (nblk + 4)));
+        // (a repeat pass had the counters cleared by the row classification; a first pass learns their number only here)
+        if (!p->warm_pass) PEM_HIP(hipMemsetAsync(p->blk_heads.p, 0, sizeof(int) * (nblk + 4), st));
         // Oversized rows.  Up to S1_XLL_MAX live products each they are sorted where they lie, one workgroup per row: two
         // launches with no shared scratch, so the chain runs on a stream of its own BESIDE the row bins.  Larger ones go through
         // the global sort, after the bins (it uses the context's scan and sort scratch).
@@ -1552,8 +1512,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
             xl_gather(1);
             PEM_LAUNCH(ctx, s1_xl_rowsort_kernel, (unsigned)(nrows_xl > 0 ? nrows_xl : 1), 1024, xl_rows, nrows_xl, p->xl_base.as<int>(),
                        p->row_lbase.as<int>(), p->sk0.as<uint64_t>(), p->sk1.as<uint64_t>(), bits_tc, p->prod_a.as<int>(), p->prod_b.as<int>(),
-                       p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(), p->block_info.as<int2>(),
-                       p->c_tile_rowptr.as<int>());
+                       p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->pair_col.as<int>(), p->blk_heads.as<int>(), p->c_tile_rowptr.as<int>());
         }
         lanes.join();
         if (n_xl > 0 && !xl_local) {   // stable radix sort on (row, tile col) over all oversized rows together
@@ -1569,9 +1528,10 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
             PEM_LAUNCH(ctx, s1_xl_rowstart_kernel, grid_for(n_xl, 256), 256, keys, n_xl, bits_tc, p->xl_rowstart.as<int>());
             PEM_LAUNCH(ctx, s1_xl_emit_kernel, grid_for(n_xl, 256), 256, keys, perm, head.as<int>(), n_xl, bits_tc, p->xl_rowstart.as<int>(),
                        p->row_lbase.as<int>(), p->prod_a.as<int>(), p->prod_b.as<int>(),
-                       p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->scratch_col.as<int>(), p->scratch_off.as<int>(),
-                       p->block_info.as<int2>(), p->c_tile_rowptr.as<int>());
+                       p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->pair_col.as<int>(), p->blk_heads.as<int>(), p->c_tile_rowptr.as<int>());
         }
+        // first pairs per 256 pairs -> C tiles in front of every 256 pairs (step 2's dense tile index)
+        PEM_TRY(exclusive_scan_i32(ctx, p->blk_heads.as<int>(), p->blk_heads.as<int>(), nblk, nullptr));
         // _C_rowPtr = exclusive scan of the per-row tile counts (spgemm.cu:1168); total = T_C
         PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_rowptr.as<int>(), p->c_tile_rowptr.as<int>(), (size_t)mt, ctx->d_scalars + 1));
         if (p->warm_pass) {
@@ -1597,14 +1557,12 @@ pem_status pem::ensure_compact(pem_ctx *ctx, const pem_cplan *cp)
 {
     pem_cplan *p = const_cast<pem_cplan *>(cp);
     if (p->compact_valid || !p->pairs_ready || p->state < 1) return PEM_OK;
-    const int mt = p->tr_hi - p->tr_lo;
-    const size_t ntc = (size_t)p->ntiles_c;
+    const size_t ntc = (size_t)p->ntiles_c, n = (size_t)p->npairs;
     PEM_ENTER(ctx);
     PEM_TRY(p->c_tile_colidx.reserve(sizeof(int) * (ntc + 4)));
     PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
-    if (mt > 0)
-        PEM_LAUNCH(ctx, s1_compact_kernel, (unsigned)mt, 256, p->c_tile_rowptr.as<int>(), mt, (long long)ntc, p->row_lbase.as<int>(),
-                   p->scratch_col.as<int>(), p->scratch_off.as<int>(), (int)p->npairs,
+    if (n > 0)
+        PEM_LAUNCH(ctx, s1_compact_kernel, (unsigned)((n + 255) / 256), 256, p->pair_col.as<int>(), (long long)n, p->blk_heads.as<int>(), (long long)ntc,
                    p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>());
     p->compact_valid = true;
     return PEM_OK;

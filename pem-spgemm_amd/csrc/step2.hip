@@ -142,25 +142,26 @@ __device__ __forceinline__ void s2_emit_rowcol(const unsigned (&cw)[8], uint8_t 
 }
 
 // ------------------------------------------------------------------------------------------
-// Step 2 (a10 offsets + a11 + a12, spgemm.cu:483-484, 499-550, 552-591) in two kernels over the row-local
-// step-1 scratch.  Step 1 leaves, for every live product slot s in [0, P): scratch_col[s] = tile column of the
-// C tile whose pair list starts there (or -1: no tile starts in this slot), scratch_off[s] = first pair of
-// that tile (a gap slot holds the end of its row's pairs, so the end of any tile's pairs is scratch_off[s+1]).
-// A row's tiles sit at the front of the row's slot range in ascending column order, so the valid slots, read
-// in slot order, ARE the C tile list in the reference's order.
+// Step 2 (a10 offsets + a11 + a12, spgemm.cu:483-484, 499-550, 552-591) in two kernels over step 1's pair stream.
+// Step 1 leaves the live pairs in their final order (pairs_a / pairs_b: sorted by C tile, ascending k inside a tile) and,
+// per pair, pair_col[p] = tile column of its C tile, sign bit set on the FIRST pair of every C tile; and per 256 pairs the
+// number of first pairs among them (scanned: blk_base).  So a C tile's dense index is
+//     t = blk_base[p >> 8] + (first pairs before p inside its 256)
+// with no scan over pairs and no dependence between workgroups.
 //
-// s2_tiles_kernel, one slot per lane, 256 slots per block:
-//   index   the tile's index t = number of valid slots before it = (valid slots before the block) + ballot rank.
-//           Step 1 notes for every block boundary the tile row it falls in and how far into the row's slots
-//           (block_info); with _C_rowPtr that gives the first term in three scalar loads -- no scan over slots,
-//           no dependence between blocks.
-//   mask    boolean product over the tile's pairs (two 16-byte loads per operand tile)
-//   out     _C_tileColIdx[t], pair offsets[t], Ctiles_mask[8t..] straight into the reference's dense layout --
-//           this replaces s1_compact -- and the entry count of every 256 tiles (one integer atomic per wave and
-//           group) for the entry offsets.
+// s2_tiles_kernel, ONE PAIR PER LANE (round 4; rounds 2-3: one C tile per lane, each lane walking its tile's pair list --
+// 1 325 vector instructions per wave where a lane's useful share was ~110, because a wave ran at the pace of its longest
+// list, and one pair's gathers in flight per lane).  One wave per 256 pairs, four trips of 64:
+//   mask    every lane forms the 16x16 boolean product of ITS pair (two 16-byte loads per operand tile); the products of a
+//           C tile's pairs -- consecutive lanes -- are OR-ed toward the tile's first pair: a few shift-and-OR steps on the
+//           vector ALU's data-parallel paths where the tiles hold few pairs (1.25 on average on webbase-1M: one or two
+//           steps), a six-step doubling by shuffles where they hold many (band matrices).  A tile that runs over the end of
+//           a trip is carried in registers; one that runs over the end of the wave's 256 pairs is finished by the wave that
+//           holds its first pair (it reads on), and the next wave skips the pairs in front of its first first-pair.
+//   out     _C_tileColIdx[t], pair offsets[t], Ctiles_mask[8t..] straight into the reference's dense layout, the 2-byte
+//           entry count, and the entry count of every 256 tiles (at most two integer atomics per wave).
 // (one small scan of the 256-tile group counts in between)
-// s2_entries_kernel, one tile per lane: perTileNnz offsets from the group base + a block scan of the masks'
-//   popcounts, the (r<<4|c) bytes, and step 3's chunk index -- replacing the 3-launch scan over all tiles.
+// s2_entries_kernel / s2_offsets_kernel: perTileNnz offsets from the group base, (the (r<<4|c) bytes,) step 3's chunk index.
 //
 // Measured and dropped: carrying (tiles, entries) through a decoupled look-back inside ONE kernel.  Flat window
 // of 64 blocks: 1.27 ms (2000 blocks in flight = 30 round trips of ~2 us agent-scope loads behind the nearest
@@ -170,96 +171,129 @@ __device__ __forceinline__ void s2_emit_rowcol(const unsigned (&cw)[8], uint8_t 
 // with every block polling from its first cycle, 0.78 ms with the look-back moved behind the mask loop; without
 // any look-back the same kernel takes 0.36 ms.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned s2_wave_shl1(unsigned v)   // lane i <- lane i + 1 (lane 63 <- 0), on the DPP path
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true);
+}
 
-__global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ scratch_col, const int *__restrict__ scratch_off, long long nslots,
-                                                       const int2 *__restrict__ block_info, const int *__restrict__ c_rowptr,
-                                                       const int *__restrict__ pairs_a, const int *__restrict__ pairs_b,
+__global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ pair_col, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b,
+                                                       long long npairs, const int *__restrict__ blk_base,
                                                        const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks, long long ntc,
                                                        int *__restrict__ c_colidx, int *__restrict__ pairs_offset, uint32_t *__restrict__ c_mask,
                                                        int *__restrict__ group_nnz, uint16_t *__restrict__ c_cnt)
 {
     __shared__ unsigned bl[8][256];
-    __shared__ int w_tiles[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int blk = blockIdx.x;
-    // valid slots before this block: the tiles of all earlier tile rows + those of the boundary row that lie before it
-    const int2 bi = block_info[blk];                         // (tile row of slot 256 blk, that slot's position in the row's range)
-    const int row_t0 = c_rowptr[bi.x], row_tiles = c_rowptr[bi.x + 1] - row_t0;
-    const long long t_blk = (long long)row_t0 + (bi.y < row_tiles ? bi.y : row_tiles);
-    const long long s = (long long)blk * 256 + tid;
-    int col = -1, p0 = 0, p1 = 0;
-    if (s < nslots) {
-        col = scratch_col[s];
-        if (col >= 0) {
-            p0 = scratch_off[s];
-            p1 = s + 1 < nslots ? scratch_off[s + 1] : (int)nslots;
-        }
-    }
-    const bool valid = col >= 0;
-    const unsigned long long vb = __ballot(valid);
-    if (lane == 0) w_tiles[wave] = __popcll(vb);
-    if (blk == 0 && tid == 0) pairs_offset[ntc] = (int)nslots;   // closing pair offset
-    __syncthreads();
-    int tile_off = __popcll(vb & ((1ull << lane) - 1ull));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long long w = (long long)blockIdx.x * 4 + (tid >> 6);          // the wave's 256 pairs
+    const long long p_lo = w * 256;
+    if (p_lo >= npairs) return;
+    if (w == 0 && lane == 0) pairs_offset[ntc] = (int)npairs;            // closing pair offset
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    long long t_next = blk_base[w];                                      // dense index of the next C tile that starts in these pairs
+    const long long g0 = t_next / S2_GROUP;                              // the wave's tiles are consecutive: they span at most two groups
+    int gs0 = 0, gs1 = 0;                                                // entries this lane stored, by group
+    // the C tile left open at the end of a trip (wave-uniform)
+    bool open = false;
+    unsigned ccw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long c_t = 0;
+    int c_j = 0, c_p0 = 0;
+    auto store_tile = [&](const long long t, const int j, const int p0, const unsigned (&cw)[8]) {
+        int nnz_t = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
-        if (w < wave) tile_off += w_tiles[w];
-    const long long t = t_blk + tile_off;
-    // the masks
-    unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // natural layout: cw[q] = row 2q | row 2q+1 << 16
-    // the pair list is walked with the next pair's masks and the one after's ids already in flight: a lane's chain per pair
-    // is then one gather deep instead of two (tiles of a band times a band hold 30+ pairs)
-    if (p0 < p1) {
-        S2Masks cur = s2_load_masks(a_masks, b_masks, pairs_a[p0], pairs_b[p0]);
-        int na = 0, nb = 0;
-        if (p0 + 1 < p1) {
-            na = pairs_a[p0 + 1];
-            nb = pairs_b[p0 + 1];
+        for (int q = 0; q < 8; ++q) nnz_t += __popc(cw[q]);
+        if (t / S2_GROUP == g0) gs0 += nnz_t; else gs1 += nnz_t;
+        c_colidx[t] = j;
+        pairs_offset[t] = p0;
+        if (c_cnt) c_cnt[t] = (uint16_t)nnz_t;      // the entry offsets then come from 2 bytes per tile, not from its 32-byte mask
+        // reference packing: word q = (row 2q) << 16 | row 2q+1  (spgemm.cu:533-543)
+        *reinterpret_cast<uint4 *>(c_mask + 8 * t) = make_uint4((cw[0] << 16) | (cw[0] >> 16), (cw[1] << 16) | (cw[1] >> 16),
+                                                                (cw[2] << 16) | (cw[2] >> 16), (cw[3] << 16) | (cw[3] >> 16));
+        *reinterpret_cast<uint4 *>(c_mask + 8 * t + 4) = make_uint4((cw[4] << 16) | (cw[4] >> 16), (cw[5] << 16) | (cw[5] >> 16),
+                                                                    (cw[6] << 16) | (cw[6] >> 16), (cw[7] << 16) | (cw[7] >> 16));
+    };
+    for (long long pb = p_lo; pb < npairs; pb += 64) {
+        const bool over = pb >= p_lo + 256;                              // past the wave's own pairs: only the open tile is still ours
+        if (over && !open) break;
+        const long long p = pb + lane;
+        const bool valid = p < npairs;
+        const int col = valid ? pair_col[p] : (int)0x80000000;           // (past the end of the pairs: a first pair, which closes the open tile)
+        const bool head = col < 0;
+        const unsigned long long H = __ballot(head);
+        const int f = H ? __builtin_ctzll(H) : 64;                       // the trip's first first-pair
+        // my pair is this wave's if a tile of ours covers it: the open tile covers the lanes in front of f, tiles that start in
+        // the trip cover the rest -- unless the wave is past its own 256 pairs
+        const bool mine = valid && (lane < f ? open : !over);
+        unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // natural layout: cw[q] = row 2q | row 2q+1 << 16
+        if (mine) {
+            const S2Masks m = s2_load_masks(a_masks, b_masks, pairs_a[p], pairs_b[p]);
+            s2_pair_mask(m, bl, tid, cw);
         }
-        for (int p = p0; p < p1; ++p) {
-            S2Masks nxt = cur;
-            int nna = 0, nnb = 0;
-            if (p + 1 < p1) {
-                nxt = s2_load_masks(a_masks, b_masks, na, nb);
-                if (p + 2 < p1) {
-                    nna = pairs_a[p + 2];
-                    nnb = pairs_b[p + 2];
+        // OR toward the first pair of every tile: lane i absorbs lane i + 1 while lane i + 1 is a further pair of the same tile
+        const unsigned long long N = __ballot(mine && !head);            // absorbed lanes
+        const bool absorb = lane < 63 && ((N >> (lane + 1)) & 1ull);
+        int longest = 0;
+        for (unsigned long long m = N; m; m = N & (m << 1)) ++longest;   // longest run of absorbed lanes
+        if (longest <= 8) {
+            for (int it = 0; it < longest; ++it) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const unsigned nx = s2_wave_shl1(cw[q]);
+                    cw[q] |= absorb ? nx : 0u;
                 }
             }
-            s2_pair_mask(cur, bl, tid, cw);
-            cur = nxt;
-            na = nna;
-            nb = nnb;
+        } else {
+            // lanes behind me in my tile (within the trip): the run of absorbed lanes that follows
+            const unsigned long long after = lane < 63 ? (~N >> (lane + 1)) | (1ull << (63 - lane)) : 1ull;
+            const int reach = __builtin_ctzll(after);
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const unsigned nx = (unsigned)__shfl_down((int)cw[q], d, 64);
+                    cw[q] |= reach >= d ? nx : 0u;
+                }
+            }
+        }
+        if (open) {
+            if (f > 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ccw[q] |= (unsigned)__builtin_amdgcn_readlane((int)cw[q], 0);
+            }
+            if (f < 64) {                                                // a first pair follows: the open tile is complete
+                if (lane == 0) store_tile(c_t, c_j, c_p0, ccw);
+                open = false;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ccw[q] = 0;
+            }
+        }
+        if (over) continue;
+        // tiles that start in this trip: all but the last are complete (the next first pair follows them inside the trip); the
+        // last one stays open -- whether a further pair of it follows is only known in the next trip
+        const unsigned long long Hv = H & __ballot(valid);
+        if (Hv) {
+            const int hl = 63 - __builtin_clzll(Hv);
+            const long long t = t_next + __popcll(Hv & lt);
+            if (head && valid && lane != hl) store_tile(t, col & 0x7FFFFFFF, (int)p, cw);
+            c_t = t_next + __popcll(Hv) - 1;
+            c_j = __builtin_amdgcn_readlane(col, hl) & 0x7FFFFFFF;
+            c_p0 = (int)(pb + hl);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ccw[q] = (unsigned)__builtin_amdgcn_readlane((int)cw[q], hl);
+            open = true;
+            t_next += __popcll(Hv);
         }
     }
-    int nnz_t = 0;
+    if (open && lane == 0) store_tile(c_t, c_j, c_p0, ccw);
+    // entry counts per group of S2_GROUP tiles
 #pragma unroll
-    for (int q = 0; q < 8; ++q) nnz_t += __popc(cw[q]);
-    const bool store = valid && t < ntc;          // (t < ntc always: both count the same valid slots)
-    // entry counts per group of S2_GROUP tiles: a wave's tiles are consecutive, so they span at most two groups
-    {
-        const long long t_first = __shfl(t, vb ? __builtin_ctzll(vb) : 0, 64);
-        const long long g0 = t_first / S2_GROUP;
-        int c0 = (store && t / S2_GROUP == g0) ? nnz_t : 0, c1 = (store && t / S2_GROUP != g0) ? nnz_t : 0;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            c0 += __shfl_xor(c0, d, 64);
-            c1 += __shfl_xor(c1, d, 64);
-        }
-        if (lane == 0 && vb) {
-            if (c0) atomicAdd(&group_nnz[g0], c0);
-            if (c1) atomicAdd(&group_nnz[g0 + 1], c1);
-        }
+    for (int d = 32; d > 0; d >>= 1) {
+        gs0 += __shfl_xor(gs0, d, 64);
+        gs1 += __shfl_xor(gs1, d, 64);
     }
-    if (!store) return;
-    c_colidx[t] = col;
-    pairs_offset[t] = p0;
-    if (c_cnt) c_cnt[t] = (uint16_t)nnz_t;      // the entry offsets then come from 2 bytes per tile, not from its 32-byte mask
-    // reference packing: word q = (row 2q) << 16 | row 2q+1  (spgemm.cu:533-543)
-    *reinterpret_cast<uint4 *>(c_mask + 8 * t) = make_uint4((cw[0] << 16) | (cw[0] >> 16), (cw[1] << 16) | (cw[1] >> 16),
-                                                            (cw[2] << 16) | (cw[2] >> 16), (cw[3] << 16) | (cw[3] >> 16));
-    *reinterpret_cast<uint4 *>(c_mask + 8 * t + 4) = make_uint4((cw[4] << 16) | (cw[4] >> 16), (cw[5] << 16) | (cw[5] >> 16),
-                                                                (cw[6] << 16) | (cw[6] >> 16), (cw[7] << 16) | (cw[7] >> 16));
+    if (lane == 0) {
+        if (gs0) atomicAdd(&group_nnz[g0], gs0);
+        if (gs1) atomicAdd(&group_nnz[g0 + 1], gs1);
+    }
 }
 
 // a11's offsets + a12 (spgemm.cu:546, 1288, 552-591), one C tile per lane, S2_GROUP tiles per block: entry offsets =
@@ -426,7 +460,7 @@ pem_status pem::step2_impl(pem_ctx *ctx, pem_cplan *p)
         PEM_TRY(p->pairs_offset.reserve(sizeof(int) * (ntc + 4)));
         if (n > 0) {
             // entry counts of every S2_GROUP tiles, accumulated by s2_tiles_kernel
-            const size_t nblk = (n + 255) / 256, ngroups = (ntc + S2_GROUP - 1) / S2_GROUP;
+            const size_t ngroups = (ntc + S2_GROUP - 1) / S2_GROUP;
             PEM_TRY(p->group_nnz.reserve(sizeof(int) * (ngroups + 4)));
             // (step 1's reset clears the counters of a repeat pass; the note holds for ONE step 2 -- a second step 2 on the
             // same step-1 result, through the step-wise API, must not add onto the scanned counts of the first)
@@ -441,10 +475,10 @@ pem_status pem::step2_impl(pem_ctx *ctx, pem_cplan *p)
             const bool decode = p->opt_decode && !deep;
             p->s3_decode = decode;
             if (decode) PEM_TRY(p->c_tile_cnt.reserve(sizeof(uint16_t) * (ntc + 8)));
-            PEM_LAUNCH(ctx, s2_tiles_kernel, (unsigned)nblk, 256, p->scratch_col.as<int>(), p->scratch_off.as<int>(), (long long)n,
-                       p->block_info.as<int2>(), p->c_tile_rowptr.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), A->masks.as<uint16_t>(),
-                       B->masks.as<uint16_t>(), (long long)ntc, p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>(), p->c_mask.as<uint32_t>(),
-                       group_nnz, decode ? p->c_tile_cnt.as<uint16_t>() : (uint16_t *)nullptr);
+            PEM_LAUNCH(ctx, s2_tiles_kernel, (unsigned)((n + 1023) / 1024), 256, p->pair_col.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
+                       (long long)n, p->blk_heads.as<int>(), A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), (long long)ntc,
+                       p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>(), p->c_mask.as<uint32_t>(), group_nnz,
+                       decode ? p->c_tile_cnt.as<uint16_t>() : (uint16_t *)nullptr);
             PEM_TRY(exclusive_scan_i32(ctx, group_nnz, group_nnz, ngroups, ctx->d_scalars + 2));
             if (p->warm_pass) {
                 nnzc = p->w_nnz;
