@@ -516,9 +516,10 @@ def main(argv=None):
         def bail():
             if emitted.is_set():
                 return
-            state["exchange"] = {"error": "the exchange legs did not finish within %d s; metric and roofline above are complete" % WATCHDOG_S}
+            state["exchange"] = {"error": "the exchange legs did not finish within %d s (leg in flight: %s); metric and roofline above are complete"
+                                          % (WATCHDOG_S, state.get("leg", "?"))}
             emit()
-            os._exit(0)
+            os._exit(3)                                           # a hung exchange is a failed run: the launcher and the driver must see it
         watchdog = threading.Timer(WATCHDOG_S, bail)
         watchdog.daemon = True
         watchdog.start()
@@ -526,6 +527,7 @@ def main(argv=None):
     exchange_ms, exchange_error = None, None
     if gather:
         try:
+            state["leg"] = "sequential gather"
             exchange()                                            # warm: communicators, receive buffers
             exchange_ms = timed(exchange, args.steps) * 1e3 / max(args.steps, 1)
         except Exception as e:                                    # noqa: BLE001 -- keep the headline line
@@ -542,6 +544,7 @@ def main(argv=None):
     if gather and grid is None and nchunks > 0 and not aat:
       try:
           cb = pkg.split_tile_rows(ctx, A, B, world * nchunks)
+          state["leg"] = "pipelined gather"
           crb = mg.ChunkedRowBlock(pkg, ctx, A, B, cb, rank, nchunks, torch_dt, dst=0)
           crb.run_pass()                                            # sizes + staging buffers; plans warm up
           crb.run_pass()

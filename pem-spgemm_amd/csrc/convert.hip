@@ -306,6 +306,8 @@ extern "C" pem_status pem_ctx_create_on_stream(int device, void *stream, pem_ctx
     for (auto &a : ctx->aux) PEM_HIP(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
     const char *graph_env = getenv("PEM_GRAPH");   // default for pem_set_graph_replay (tools, CLI)
     ctx->graph_replay = graph_env && !strcmp(graph_env, "1");
+    const char *gd_env = getenv("PEM_DEBUG_GRAPH_DESTROY");   // diagnostic, tools/graph_churn.py: see retire_graph
+    ctx->dbg_destroy_graphs = gd_env && !strcmp(gd_env, "1");
     PEM_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     for (auto &e : ctx->ev_join) PEM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     PEM_HIP(hipStreamSynchronize(ctx->stream));
@@ -964,9 +966,12 @@ extern "C" pem_status pem_tiled_load(pem_ctx *ctx, const char *path, const pem_c
 
 extern "C" pem_status pem_tiled_destroy(pem_ctx *ctx, pem_tiled *t)
 {
+    // the tiling's blocks go back to the arena and may be handed out again at once: whatever still reads them must be done
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
+    } else {
+        (void)hipDeviceSynchronize();   // (no context given: the caller's current device)
     }
     delete t;
     return PEM_OK;

@@ -75,6 +75,10 @@ public:
     };
     Stats stats();
     const int device;
+    // bumped whenever a buffer of this arena is (re)allocated or freed, or slabs are trimmed: a captured pass (hipGraph) bakes
+    // buffer addresses in.  Per arena (round 4): a process-wide counter made every allocation in ANY context retire every plan's
+    // captured graph.  Atomic: handles may be destroyed by another thread than their context's.
+    std::atomic<unsigned long long> generation{0};
 
 private:
     struct Slab {
@@ -99,13 +103,6 @@ struct ArenaBind {
     ~ArenaBind() { current_arena() = prev; }
 };
 
-// bumped whenever any device buffer is (re)allocated or freed: a captured pass (hipGraph) bakes buffer addresses in
-inline std::atomic<unsigned long long> &alloc_generation()   // atomic: one host thread per device in multi-GPU runs
-{
-    static std::atomic<unsigned long long> gen{0};
-    return gen;
-}
-
 // Grow-only device buffer carved out of the bound arena.  Contents are NOT preserved across a growth.
 struct DevBuf {
     void *p = nullptr;
@@ -124,7 +121,7 @@ struct DevBuf {
     {
         if (p) {
             arena->free(p);
-            ++alloc_generation();
+            ++arena->generation;
         }
         p = nullptr;
         cap = 0;
@@ -140,7 +137,7 @@ struct DevBuf {
             return PEM_E_INVALID;
         }
         size_t want = (bytes + 255) & ~size_t(255);
-        ++alloc_generation();
+        ++a->generation;
         p = a->alloc(want);
         if (!p) return PEM_E_NOMEM;
         arena = a;
@@ -181,6 +178,7 @@ struct pem_ctx {
     // pinned host page for scalar read-backs (replaces the reference's racy pageable
     // cudaMemcpyAsync of _C_nnz / d_pairs_count / C_nnz)
     std::vector<hipGraphExec_t> retired_graphs;   // graph executables plans no longer use: destroyed with the context (see retire_graph)
+    bool dbg_destroy_graphs = false;   // diagnostic (PEM_DEBUG_GRAPH_DESTROY=1 when the context is created): destroy them at once instead
     int cu_count = 0;                  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     int64_t *h_scalars = nullptr;      // 64 slots
     volatile int *h_flags = nullptr;   // the status flags of a repeat pass, written by the pass's checking thread (host view; slots 56..)
@@ -342,7 +340,7 @@ struct pem_cplan {
     // sizes: it skips the three host read-backs and a device-side check compares them at the end instead.
     pem_ctx *owner = nullptr;              // the context the plan was created on
     hipGraphExec_t graph_exec = nullptr;   // PEM_GRAPH=1: the captured warm pass
-    unsigned long long graph_gen = 0;      // alloc_generation() at capture time
+    unsigned long long graph_gen = 0;      // the context arena's generation at capture time
     bool graph_failed = false;             // capture or instantiation failed once: plain launches from then on
     bool warm = false, warm_pass = false;
     int64_t w_P = 0, w_Pall = 0, w_TC = 0, w_nnz = 0;

@@ -165,6 +165,7 @@ pem_status arena_phase(const std::shared_ptr<Arena> &arena, std::initializer_lis
 void Arena::trim()
 {
     std::lock_guard<std::mutex> lock(mu);
+    ++generation;
     for (size_t i = 0; i < slabs.size();) {
         auto f = free_blocks.find(slabs[i].base);
         if (f != free_blocks.end() && f->second == slabs[i].size) {

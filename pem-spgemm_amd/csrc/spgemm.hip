@@ -92,18 +92,31 @@ extern "C" pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const p
     return PEM_OK;
 }
 
-// A plan's instantiated graph is not destroyed when the plan lets go of it but when its CONTEXT goes: the HIP runtime of this image
-// (ROCm 7.x) keeps state across the graph executables of a process that a later hipGraphLaunch trips over once earlier ones have
-// been destroyed -- a segmentation fault in hip::Graph::UpdateStreams, seen after 8-12 create / replay / destroy rounds of plans
-// with forked streams (tools/split_tune_emulate.py).  Executables are small; a context that outlives thousands of plans can call
-// pem_ctx_trim, which does not touch them either -- they go with pem_ctx_destroy.
+// A plan's instantiated graph is not destroyed the moment the plan lets go of it.  Round 3 saw hipGraphLaunch fault (a segmentation
+// fault inside the runtime, hip::Graph::UpdateStreams by the rocgdb backtrace of the time, which was not kept) after 8-12 create /
+// capture / replay / destroy rounds of plans with forked streams (tools/split_tune_emulate.py).  Round 4 ran that script once under
+// rocgdb with executables destroyed at once (PEM_DEBUG_GRAPH_DESTROY=1) -- on this round's library and on the round-3 tree: 32
+// plans each, no fault (gpurun_out of the round).  The builder-side candidates were read through and do not hold:
+// every auxiliary stream is joined into the main one inside the capture, so synchronising the main stream (pem_spgemm does, before it
+// returns, and pem_cplan_destroy again) covers all captured work; the fork / join events are only edges of the captured graph --
+// an instantiated executable does not reference them; captures are thread-local and a context is single-caller.  What round 3 had
+// and round 4 has not is FIVE streams in one capture (three bins + the oversized-row chain + main) against the runtime's four
+// hardware queues -- round 4 plans step 1 over four.  With the cause not established, executables are still retired rather than
+// destroyed in place, but the list is bounded: at S_RETIRE_MAX the device is drained and the list emptied.
+constexpr size_t S_RETIRE_MAX = 32;
 void pem::retire_graph(pem_ctx *ctx, pem_cplan *plan)
 {
     if (!plan->graph_exec) return;
-    if (ctx)
+    if (ctx && !ctx->dbg_destroy_graphs) {
         ctx->retired_graphs.push_back(plan->graph_exec);
-    else
+        if (ctx->retired_graphs.size() >= S_RETIRE_MAX && !ctx->capturing) {
+            (void)hipDeviceSynchronize();
+            for (auto ge : ctx->retired_graphs) (void)hipGraphExecDestroy(ge);
+            ctx->retired_graphs.clear();
+        }
+    } else {
         (void)hipGraphExecDestroy(plan->graph_exec);
+    }
     plan->graph_exec = nullptr;
 }
 
@@ -112,6 +125,8 @@ extern "C" pem_status pem_cplan_destroy(pem_ctx *ctx, pem_cplan *plan)
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
+    } else {
+        (void)hipDeviceSynchronize();   // (no context given: the plan's blocks still go back to its arena)
     }
     if (plan) retire_graph(ctx, plan);
     delete plan;
@@ -168,6 +183,22 @@ extern "C" pem_status pem_cplan_set_option(pem_cplan *plan, pem_option which, in
     // a repeat pass re-uses the sizes (and possibly the captured graph) of the previous one: whatever changes the kernels
     // that run or the sizes they produce starts the plan over
     plan->warm = false;
+    // ... and the step-wise API too: results of a step that ran under the old value do not feed a step that runs under the new one
+    // (step 3 derives its tile lookup from PRUNE, step 2's output depends on DECODE, ...)
+    // -- back to the last step the option does not touch
+    int keep = 3;
+    switch (which) {
+    case PEM_OPT_PRUNE: case PEM_OPT_STEP1_GLOBAL_SORT: case PEM_OPT_S1_FORCE_KEY64: case PEM_OPT_S1_XLCAP: case PEM_OPT_S1_XL_GLOBAL: keep = 0; break;
+    case PEM_OPT_WIDE: case PEM_OPT_S3_DECODE: keep = 1; break;
+    case PEM_OPT_S3_BAND: case PEM_OPT_S3_EPW: case PEM_OPT_S3_IDX64: case PEM_OPT_S3_MARK: case PEM_OPT_S3_XCD: keep = 2; break;
+    default: break;                                    // warm passes, the export variant, serial bins: no step's result changes
+    }
+    if (plan->state > keep) plan->state = keep;
+    if (keep == 0) {
+        plan->pairs_ready = false;
+        plan->compact_valid = plan->c_rowidx_valid = false;
+    }
+    if (keep <= 1) plan->c_rowptr_valid = plan->c_rowcolidx_valid = false;
     if (plan->graph_exec) {
         retire_graph(plan->owner, plan);
     }
@@ -266,7 +297,7 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
     const bool use_graph = ctx->graph_replay && plan->warm && !ctx->profiling && !plan->opt_step1_esc && plan->opt_warm;
     bool graphed = false;
     if (use_graph && !plan->graph_failed) {
-        if (plan->graph_exec && plan->graph_gen != pem::alloc_generation()) {
+        if (plan->graph_exec && plan->graph_gen != ctx->arena->generation.load()) {
             retire_graph(ctx, plan);
         }
         if (!plan->graph_exec) {   // capture; any failure falls back to plain launches for the rest of the plan's life
@@ -282,7 +313,7 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
                 ctx->capturing = false;
                 if (cs == PEM_OK && ee == hipSuccess && graph &&
                     hipGraphInstantiate(&plan->graph_exec, graph, nullptr, nullptr, 0) == hipSuccess)
-                    plan->graph_gen = pem::alloc_generation();
+                    plan->graph_gen = ctx->arena->generation.load();
                 else
                     plan->graph_exec = nullptr;
                 if (graph) (void)hipGraphDestroy(graph);
