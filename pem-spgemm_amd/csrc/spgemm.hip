@@ -84,6 +84,7 @@ extern "C" pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const p
     p->opt_s3_xcd = !env_is("PEM_S3_XCD", "0");
     p->opt_idx64 = env_is("PEM_S3_IDX64", "1");
     p->opt_mark = !env_is("PEM_S3_MARK", "0");
+    p->opt_s1_segments = !env_is("PEM_S1_SEGMENTS", "0");
     {
         const char *e = getenv("PEM_S3_EPW");
         p->opt_epw = e ? atoi(e) : 0;
@@ -165,6 +166,7 @@ static int *plan_option_slot(pem_cplan *p, pem_option which)
     case PEM_OPT_S3_XCD: return &p->opt_s3_xcd;
     case PEM_OPT_S3_IDX64: return &p->opt_idx64;
     case PEM_OPT_S3_MARK: return &p->opt_mark;
+    case PEM_OPT_S1_SEGMENTS: return &p->opt_s1_segments;
     default: return nullptr;
     }
 }
@@ -188,7 +190,8 @@ extern "C" pem_status pem_cplan_set_option(pem_cplan *plan, pem_option which, in
     // -- back to the last step the option does not touch
     int keep = 3;
     switch (which) {
-    case PEM_OPT_PRUNE: case PEM_OPT_STEP1_GLOBAL_SORT: case PEM_OPT_S1_FORCE_KEY64: case PEM_OPT_S1_XLCAP: case PEM_OPT_S1_XL_GLOBAL: keep = 0; break;
+    case PEM_OPT_PRUNE: case PEM_OPT_STEP1_GLOBAL_SORT: case PEM_OPT_S1_FORCE_KEY64: case PEM_OPT_S1_XLCAP: case PEM_OPT_S1_XL_GLOBAL:
+    case PEM_OPT_S1_SEGMENTS: keep = 0; break;
     case PEM_OPT_WIDE: case PEM_OPT_S3_DECODE: keep = 1; break;
     case PEM_OPT_S3_BAND: case PEM_OPT_S3_EPW: case PEM_OPT_S3_IDX64: case PEM_OPT_S3_MARK: case PEM_OPT_S3_XCD: keep = 2; break;
     default: break;                                    // warm passes, the export variant, serial bins: no step's result changes
@@ -287,7 +290,7 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
     auto launch_verify = [&]() {
         if (plan->verify_folded) return;   // step 2's last kernel has already compared the sizes
         const WarmCheck wc = {1, plan->w_P, plan->w_Pall, plan->w_TC, plan->w_nnz, plan->w_nxl,
-                              {plan->w_counts[0], plan->w_counts[1], plan->w_counts[2], plan->w_counts[3], plan->w_counts[4]}, nullptr};
+                              {plan->w_counts[0], plan->w_counts[1], plan->w_counts[2], plan->w_counts[3], plan->w_counts[4]}, plan->w_nsegs, nullptr};
         PEM_LAUNCH(ctx, warm_verify_kernel, 1, 1, reinterpret_cast<const long long *>(ctx->d_scalars), plan->bin_count.as<int>(), wc, ctx->d_flags);
     };
     // Graph replay (pem_set_graph_replay): a repeat pass has fixed grids, sizes and buffer addresses, so its ~28 launches,

@@ -14,19 +14,19 @@ constexpr int S2_GROUP = 256;   // C tiles per group of step 2's entry counts
 // repeat pass on an unchanged plan: the sizes the host assumed (from the previous pass) against what this pass computed
 // counters of a pass of step 1 (plan->bin_count, ints): populations of the five row bins and of the oversized rows, the
 // oversized rows' live products (total, largest row), and the allocator of the live list
-enum { BC_BIN0 = 0, BC_XL_ROWS = 5, BC_XL_TOTAL = 6, BC_XL_MAX = 7, BC_FAULT = 8, BC_BUMP = 10 /* 64-bit: ints 10-11 */, BC_INTS = 16 };
+enum { BC_BIN0 = 0, BC_XL_ROWS = 5, BC_XL_TOTAL = 6, BC_XL_MAX = 7, BC_SEGS = 8 /* segments of the big rows */, BC_FAULT = 9, BC_BUMP = 10 /* 64-bit: ints 10-11 */, BC_INTS = 16 };
 
 struct WarmCheck {
     int on;
     long long P, Pall, TC, nnz, nxl;
     int c[5];
-    int *host_flags;     // where set: the pass's status flags are left in host memory by the checking thread (no copy node after the pass)
+    int nsegs;    int *host_flags;     // where set: the pass's status flags are left in host memory by the checking thread (no copy node after the pass)
 };
 __device__ __forceinline__ void warm_check(const WarmCheck &w, const long long *__restrict__ d_scalars, const int *__restrict__ bin_count,
                                            int *__restrict__ flags)
 {
     if (d_scalars[0] != w.P || d_scalars[1] != w.TC || d_scalars[2] != w.nnz || d_scalars[3] != w.Pall || bin_count[0] != w.c[0] ||
-        bin_count[1] != w.c[1] || bin_count[2] != w.c[2] || bin_count[3] != w.c[3] || bin_count[4] != w.c[4] || bin_count[BC_XL_TOTAL] != w.nxl)
+        bin_count[1] != w.c[1] || bin_count[2] != w.c[2] || bin_count[3] != w.c[3] || bin_count[4] != w.c[4] || bin_count[BC_XL_TOTAL] != w.nxl || bin_count[BC_SEGS] != w.nsegs)
         flags[FLAG_CAPACITY] = 1;
     if (w.host_flags) {
         // the caller guarantees that nothing after this thread sets a flag in this pass (s2_offsets_kernel + step 3: none do)

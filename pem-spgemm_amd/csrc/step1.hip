@@ -175,6 +175,8 @@ constexpr int S1_CAP0 = 64, S1_CAP1 = 512, S1_CAP2 = 2048, S1_CAP3 = 8192, S1_CA
 constexpr int S1_QB0 = 6, S1_QB1 = 9, S1_QB2 = 11, S1_QB3 = 13, S1_QB4 = 15;                  // ... and the bits of a key's index field
 constexpr int S1_NLIST = 6;              // row lists: the five bins + the oversized rows
 constexpr int S1_PC1 = 64, S1_PC2 = 256, S1_PC3 = 1024;   // pieces (chunks) per row a bin's table holds (= its threads)
+constexpr int S1_SEG_T = 1024;           // keys per column-range segment of a big row (aimed at; a segment's sort holds 2048)
+constexpr int S1_XLL_MAX = 1 << 18;      // rows with more live products than this take the global sort (one workgroup -- or 256 segments -- per row would take too long)
 
 __global__ void __launch_bounds__(256) s1_total_kernel(const int *__restrict__ a_tile_colidx, int a_lo, int nA, const int *__restrict__ b_tile_rowptr,
                                                        unsigned long long *__restrict__ total)
@@ -427,7 +429,8 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
                                                           int *__restrict__ row_l, int4 *__restrict__ row_desc, int *__restrict__ row_list,
                                                           int *__restrict__ bin_count, int *__restrict__ xl_base, int *__restrict__ row_tc,
                                                           long long *__restrict__ scalars, int *__restrict__ flags, int *__restrict__ pairs_offset,
-                                                          int *__restrict__ group_nnz, int ngroups, int *__restrict__ blk_heads, int nblk)
+                                                          int *__restrict__ group_nnz, int ngroups, int *__restrict__ blk_heads, int nblk,
+                                                          int seg_on, int2 *__restrict__ seg_list)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -468,7 +471,14 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
         else if (nl <= S1_CAP2 && np <= S1_PC2) bin = 2;
         else if (nl <= S1_CAP3 && np <= S1_PC3) bin = 3;
         else if (nl <= cap4 && np <= S1_PC3) bin = 4;
+        // rows above the 2048-key bin: column-range segments, one workgroup each (list 3 holds the rows, seg_list the segments)
+        if (seg_on && bin >= 3) bin = (nl <= S1_XLL_MAX && np <= S1_PC2) ? 3 : 5;
         if (nl > xlcap) bin = 5;                                 // test hook: rows above xlcap live products take the oversized-row path
+        if (seg_on && bin == 3) {
+            const int G = (nl + S1_SEG_T - 1) / S1_SEG_T;
+            const int s0 = atomicAdd(&bin_count[BC_SEGS], G);
+            for (int g = 0; g < G; ++g) seg_list[s0 + g] = make_int2(i, g | (G << 16));
+        }
     }
     // slots by ballot + prefix popcount inside a wave, one LDS atomic per wave and bin inside the block, ONE global
     // atomic per block and bin (order inside a bin is irrelevant)
@@ -959,6 +969,201 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
     }
 }
 
+// Big rows in column-range segments.  A row of more than 2048 live products sorted by ONE workgroup is a serial chain of tens of
+// microseconds (a directory page of webbase-1M: 11 k keys, 55 us; the round-2 stand-in has a thousand rows of 2-18 k keys) on a
+// chip that runs hundreds of workgroups -- so the row is cut into G = ceil(nl / 1024) ranges of tile columns and every range gets a
+// workgroup of its own: it reads ALL the row's keys (coalesced, a few tens of KB from L2), keeps those whose tile column lies in its
+// range, in list order, and counts the keys of smaller columns -- which is where its pairs start in the row's output, no other
+// segment needed -- then sorts its keys like the 2048-key bin and emits.  The first pair of a segment opens a C tile (its column is
+// new), so the marks and counts that step 2 indexes C tiles by need nothing from the other segments either; the row's tile count is
+// summed by atomics.  Ranges are cut evenly over B's tile columns; one that holds more than 2048 keys is halved until it fits, a
+// single column with more than 2048 keys (a C tile of that many pairs) is emitted as it stands -- one column needs no sort.
+template <typename KeyT>
+__global__ void __launch_bounds__(1024) s1_rowseg_kernel(const int2 *__restrict__ seg_list, int nsegs, const int *__restrict__ a_tile_rowptr, int tr_lo,
+                                                        int a_lo, const int2 *__restrict__ aseg, const int *__restrict__ row_lbase,
+                                                        const int *__restrict__ lj, const int2 *__restrict__ lab, int tile_cols,
+                                                        int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ pair_col,
+                                                        int *__restrict__ blk_heads, int *__restrict__ row_tc)
+{
+    // (sixteen waves: every segment reads its whole row, and with four waves a directory row's 12 k keys were two dozen dependent
+    // round trips per wave -- 60 us for a segment whose sort takes four)
+    constexpr int CAP = S1_CAP2, QB = S1_QB2, THREADS = 1024, WAVES = 16, LOGT = 10;
+    __shared__ KeyT keys[CAP];
+    __shared__ unsigned gidx[CAP];       // position in the row's list of the key at every position of the segment's list
+    __shared__ unsigned psrc[S1_PC2];
+    __shared__ int pdst[S1_PC2 + 1];
+    __shared__ int wcnt[WAVES], wlow[WAVES], wsum[WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int si = blockIdx.x; si < nsegs; si += gridDim.x) {
+        const int2 sd = seg_list[si];
+        const int i = sd.x, g = sd.y & 0xFFFF, G = sd.y >> 16;
+        const int ra0 = a_tile_rowptr[tr_lo + i] - a_lo, ra1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
+        const int lp0 = row_lbase[i], nl = row_lbase[i + 1] - lp0;
+        const int c0 = ra0 / S1_CH, np = (ra1 - 1) / S1_CH - c0 + 1;       // <= THREADS: the row classification saw to that
+        {
+            unsigned src = 0;
+            int cnt = 0;
+            if (tid < np) {
+                const int c = c0 + tid;
+                const int first = ra0 > c * S1_CH ? ra0 : c * S1_CH, last = (ra1 < c * S1_CH + S1_CH ? ra1 : c * S1_CH + S1_CH) - 1;
+                const int2 s = aseg[first], e = aseg[last];
+                src = (unsigned)s.x;
+                cnt = (int)((unsigned)e.x + (unsigned)e.y - src);
+            }
+            int inc = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += o;
+            }
+            int ex = inc - cnt;
+            if (np > 64) {                               // (block-uniform)
+                if (lane == 63) wsum[wave] = inc;
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < WAVES; ++w)
+                    if (w < wave) ex += wsum[w];
+            }
+            if (tid < np) {
+                psrc[tid] = src;
+                pdst[tid] = ex;
+            }
+            if (tid == 0) pdst[np] = nl;
+        }
+        __syncthreads();
+        auto list_src = [&](const int x) {               // where position x of the row's list lies in the live list
+            const int p = np == 1 ? 0 : s1_find_a(pdst, 0, np, x);
+            return psrc[p] + (unsigned)(x - pdst[p]);
+        };
+        // every wave scans one contiguous sixteenth of the row's list
+        const int per = (((nl + WAVES - 1) / WAVES) + 63) & ~63;
+        const int x_lo = wave * per < nl ? wave * per : nl, x_hi = x_lo + per < nl ? x_lo + per : nl;
+        int tiles = 0;
+        const long long seg_lo = (long long)tile_cols * g / G, seg_hi = (long long)tile_cols * (g + 1) / G;
+        long long r_lo = seg_lo, r_hi = seg_hi;
+        while (r_lo < seg_hi) {                          // (block-uniform) ranges of the segment, normally the one
+            // keys of smaller columns, keys inside the range: counted per wave over its quarter
+            int low = 0, cnt = 0;
+            for (int x0 = x_lo; x0 < x_hi; x0 += 256) {
+                int cc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) cc[u] = lj[list_src(x0 + 64 * u + lane < x_hi ? x0 + 64 * u + lane : x_lo)];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (x0 + 64 * u + lane < x_hi) {
+                        low += cc[u] < r_lo;
+                        cnt += cc[u] >= r_lo && cc[u] < r_hi;
+                    }
+                }
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                low += __shfl_xor(low, d, 64);
+                cnt += __shfl_xor(cnt, d, 64);
+            }
+            __syncthreads();                             // (the counters of the range before are read)
+            if (lane == 0) {
+                wcnt[wave] = cnt;
+                wlow[wave] = low;
+            }
+            __syncthreads();
+            int below = 0, total = 0, wbase = 0;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                below += wlow[w];
+                if (w < wave) wbase += wcnt[w];
+                total += wcnt[w];
+            }
+            if (total > CAP && r_hi - r_lo > 1) {        // too many keys for one sort: the lower half of the range first
+                r_hi = r_lo + (r_hi - r_lo) / 2;
+                continue;
+            }
+            if (total > 0) {
+                const bool one_col = total > CAP;        // a single tile column: its keys, in list order, ARE the sorted stream
+                // the range's keys, in list order: positions from the per-wave counts, ballot ranks inside a wave
+                int run = wbase;
+                for (int x0 = x_lo; x0 < x_hi; x0 += 256) {       // four trips' loads in flight together
+                    unsigned ss[4];
+                    int cc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ss[u] = list_src(x0 + 64 * u + lane < x_hi ? x0 + 64 * u + lane : x_lo);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cc[u] = lj[ss[u]];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int x = x0 + 64 * u + lane;
+                        const bool in = x < x_hi && cc[u] >= r_lo && cc[u] < r_hi;
+                        const unsigned long long bal = __ballot(in);
+                        if (in) {
+                            const int pos = run + __popcll(bal & lt);
+                            if (one_col) {
+                                const int2 ab = lab[ss[u]];
+                                const long long o = (long long)lp0 + below + pos;
+                                pairs_a[o] = ab.x;
+                                pairs_b[o] = ab.y;
+                                pair_col[o] = cc[u] | (pos == 0 ? (int)0x80000000 : 0);
+                            } else {
+                                keys[pos] = (KeyT((unsigned)cc[u]) << QB) | KeyT(pos);
+                                gidx[pos] = (unsigned)x;
+                            }
+                        }
+                        run += __popcll(bal);
+                    }
+                }
+                if (one_col) {
+                    if (tid == 0) {
+                        atomicAdd(&blk_heads[((long long)lp0 + below) >> 8], 1);
+                        ++tiles;
+                    }
+                } else {
+                    int upto = THREADS;
+                    while (upto < total) upto <<= 1;
+                    for (int x = total + tid; x < upto; x += THREADS) keys[x] = ~KeyT(0);
+                    __syncthreads();
+                    {
+                        S1Row<KeyT, CAP, QB, THREADS> row;
+                        row.keys = keys;
+                        if (total <= THREADS)
+                            row.template sort_regs<1, LOGT>(tid);
+                        else
+                            row.template sort_regs<2, LOGT>(tid);
+                    }
+                    const int nseg64 = (total + 63) >> 6;
+                    for (int q = wave; q < nseg64; q += WAVES) {
+                        const int s = 64 * q + lane;
+                        const bool valid = s < total;
+                        int j = 0;
+                        int2 ab = make_int2(0, 0);
+                        bool head = false;
+                        if (valid) {
+                            const KeyT key = keys[s];
+                            j = (int)(key >> QB);
+                            head = s == 0 || (int)(keys[s - 1] >> QB) != j;
+                            ab = lab[list_src((int)gidx[(int)(key & KeyT((1u << QB) - 1u))])];
+                        }
+                        const unsigned long long bal = __ballot(head);
+                        const long long o = (long long)lp0 + below + s;
+                        if (valid) {
+                            pairs_a[o] = ab.x;
+                            pairs_b[o] = ab.y;
+                            pair_col[o] = j | (head ? (int)0x80000000 : 0);
+                        }
+                        if (lane == 0) {
+                            s1_note_heads(blk_heads, (long long)lp0 + below + 64 * q, bal);
+                            tiles += __popcll(bal);
+                        }
+                    }
+                }
+            }
+            r_lo = r_hi;
+            r_hi = seg_hi;
+        }
+        if (lane == 0 && tiles) atomicAdd(&row_tc[i], tiles);
+        __syncthreads();                                 // the tables are rebuilt by the next segment
+    }
+}
+
 // Oversized rows (above the largest LDS bin, or more pieces than a bin's table holds): the row's pieces are copied into the
 // row's own stretch of the 64-bit key buffer -- key (tile column, slot) for the per-row sort, (row, tile column) for the global
 // one -- with the (A tile, B tile) of every product beside it; any number of pieces, 1024 per trip.
@@ -1066,7 +1271,6 @@ __global__ void s1_xl_emit_kernel(const uint64_t *__restrict__ keys, const uint3
 // tile-column bits with the keys in global memory (L2-resident: a row is a few hundred KB) -- per-wave digit histograms in LDS,
 // one scan of the 16 x 256 counters, ballot-ranked scatter, as in the 16-wave LDS bins -- followed by the same emit as
 // s1_rowsort_kernel.  One launch.
-constexpr int S1_XLL_MAX = 1 << 18;     // rows with more live products than this keep the global path (one workgroup would take too long)
 __global__ void __launch_bounds__(1024) s1_xl_rowsort_kernel(const int *__restrict__ xl_rows, int nrows_xl, const int *__restrict__ xl_base,
                                                              const int *__restrict__ row_lbase, uint64_t *k0, uint64_t *k1, int bits_tc,
                                                              const int *__restrict__ prod_a, const int *__restrict__ prod_b,
@@ -1289,8 +1493,9 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
 // behind the row classification and joined before the row-count scan.  Four, because the runtime feeds four hardware queues: a
 // fifth stream shares a queue with one of the others, and in round 4's first cut the one-key-per-lane kernel (62 k waves, the
 // bulk of the work) landed behind the 32768-key bin (five workgroups, 61 us) on the main stream's queue.  The plan, by what
-// each kernel takes alone on webbase-1M:   main: tiny rows (25 us), then the 512-key bin (21)   aux 0: 32768-key bin (61)
-//                                          aux 1: 8192-key bin (35)                              aux 2: 2048-key bin (28), then the oversized rows
+// each kernel takes alone on webbase-1M:   main: tiny rows (30 us)   aux 0: the big rows' segments (34)   aux 1: 512-key bin (21)
+//                                          aux 2: 2048-key bin (28), then the oversized rows
+// (PEM_OPT_S1_SEGMENTS = 0:  main: tiny rows, then the 512-key bin   aux 0: 32768-key bin (61)   aux 1: 8192-key bin (35)   aux 2: as above)
 struct S1Lanes {
     pem_ctx *ctx;
     hipStream_t main_stream;
@@ -1319,7 +1524,7 @@ struct S1Lanes {
     }
 };
 
-static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const int *counts, int mt, int bits_tc, bool force64)
+static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const int *counts, int mt, int bits_tc, bool force64, int nsegs)
 {
     const pem_tiled *A = p->A;
     int *rl = p->row_list.as<int>();
@@ -1336,6 +1541,21 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
             PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<" #CAP ",key64>", (s1_rowsort_kernel<uint64_t, CAP, QB, THREADS>), counts[BIN],      \
                              THREADS, PEM_ROWSORT_ARGS(BIN, QB));                                                                        \
     } while (0)
+    if (p->opt_s1_segments) {
+        if (nsegs > 0) {                   // rows above the 2048-key bin, one workgroup per column-range segment
+            lanes.on(1);
+            if (bits_tc + S1_QB2 <= 32 && !force64)
+                PEM_LAUNCH_NAMED(ctx, "s1_rowseg_kernel", (s1_rowseg_kernel<uint32_t>), nsegs, 1024, p->seg_list.as<int2>(), nsegs, A->tile_rowptr.as<int>(),
+                                 p->tr_lo, p->a_lo, p->aseg.as<int2>(), p->row_lbase.as<int>(), p->live_j.as<int>(), p->live_ab.as<int2>(),
+                                 p->B->tile_cols, p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->pair_col.as<int>(), p->blk_heads.as<int>(),
+                                 p->c_tile_rowptr.as<int>());
+            else
+                PEM_LAUNCH_NAMED(ctx, "s1_rowseg_kernel<key64>", (s1_rowseg_kernel<uint64_t>), nsegs, 1024, p->seg_list.as<int2>(), nsegs,
+                                 A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->aseg.as<int2>(), p->row_lbase.as<int>(), p->live_j.as<int>(),
+                                 p->live_ab.as<int2>(), p->B->tile_cols, p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->pair_col.as<int>(),
+                                 p->blk_heads.as<int>(), p->c_tile_rowptr.as<int>());
+        }
+    } else {
     if (counts[4] > 0) {                   // (only populated where 32-bit keys hold a 15-bit index: see the row classification's cap4)
         lanes.on(1);
         PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<32768>", (s1_rowsort_kernel<uint32_t, S1_CAP4, S1_QB4, 1024>), counts[4], 1024,
@@ -1344,6 +1564,7 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
     if (counts[3] > 0) {
         lanes.on(2);
         PEM_ROWSORT(3, 8192, S1_QB3, 1024);
+    }
     }
     if (counts[2] > 0) {
         lanes.on(3);
@@ -1356,7 +1577,7 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
                    p->blk_heads.as<int>(), p->c_tile_rowptr.as<int>());
     }
     if (counts[1] > 0) {
-        lanes.on(0);
+        lanes.on(p->opt_s1_segments ? 2 : 0);   // (with the big rows in segments the second auxiliary stream is free: every bin has a queue of its own)
         PEM_ROWSORT(1, 512, S1_QB1, 64);
     }
     lanes.on(0);
@@ -1424,6 +1645,10 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         p->group_nnz_cleared = true;
     }
     const int nblk_reset = p->warm_pass ? (int)(p->w_P / 256 + 1) : 0;   // (the buffer is in place since the plan's first pass)
+    // rows above the 2048-key bin are sorted in column-range segments (PEM_OPT_S1_SEGMENTS = 0: one workgroup per row, the 8192- and
+    // 32768-key bins); a row has at most nl / 1024 + 1 segments
+    const int seg_on = p->opt_s1_segments != 0;
+    PEM_TRY(p->seg_list.reserve(sizeof(int2) * (ncap / S1_SEG_T + (size_t)mt + 16)));
     const int prune = p->opt_prune;
     PEM_LAUNCH(ctx, s1_expand_kernel, (unsigned)(nchunks > 0 ? nchunks : 1), 64 * S1_XW, A->tile_colidx.as<int>(), A->tile_occ.as<uint32_t>(),
                p->a_lo, nA, B->tile_rowptr.as<int>(), B->tile_colocc.as<int2>(), prune, p->bin_count.as<int>(), (unsigned long long)ncap,
@@ -1437,15 +1662,16 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
                    p->chunk_seg.as<int2>(), p->chunk_n.as<long long>(), tiny_ok, cap4, xlcap, p->row_lbase.as<int>(), p->row_desc.as<int4>(),
                    p->row_list.as<int>(), p->bin_count.as<int>(), p->xl_base.as<int>(), p->c_tile_rowptr.as<int>(),
                    reinterpret_cast<long long *>(ctx->d_scalars), ctx->d_flags, p->pairs_offset.as<int>(), p->group_nnz.as<int>(), ngroups_reset,
-                   p->blk_heads.as<int>(), nblk_reset);
+                   p->blk_heads.as<int>(), nblk_reset, seg_on, p->seg_list.as<int2>());
     }
     PEM_TRY(exclusive_scan_i32(ctx, p->row_lbase.as<int>(), p->row_lbase.as<int>(), (size_t)mt, ctx->d_scalars));
     // one read-back: P, the bin populations and the product total of the oversized rows
     int64_t P = 0, Pall = 0;
     int counts[5];
     size_t n_xl;
-    int nrows_xl = 0, max_xl = 0;
+    int nrows_xl = 0, max_xl = 0, nsegs = 0;
     if (p->warm_pass) {
+        nsegs = p->w_nsegs;
         max_xl = p->w_max_xl;
         P = p->w_P;
         Pall = p->w_Pall;
@@ -1454,7 +1680,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         nrows_xl = p->w_nrows_xl;
     } else {
         int *hb = reinterpret_cast<int *>(ctx->h_scalars + 32);
-        PEM_HIP(hipMemcpyAsync(hb, p->bin_count.p, sizeof(int) * 8, hipMemcpyDeviceToHost, st));
+        PEM_HIP(hipMemcpyAsync(hb, p->bin_count.p, sizeof(int) * BC_FAULT, hipMemcpyDeviceToHost, st));
         int64_t sc[4];
         PEM_TRY(read_scalars(ctx, ctx->d_scalars, 4, sc));
         P = sc[0];
@@ -1463,6 +1689,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         nrows_xl = p->w_nrows_xl = hb[BC_XL_ROWS];
         n_xl = (size_t)hb[BC_XL_TOTAL];
         max_xl = p->w_max_xl = hb[BC_XL_MAX];
+        nsegs = p->w_nsegs = hb[BC_SEGS];
         p->w_nxl = (int64_t)n_xl;
         p->w_P = P;
         p->w_Pall = Pall;
@@ -1506,7 +1733,7 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
                        p->sk0.as<uint64_t>(), p->sv0.as<uint32_t>(), p->prod_a.as<int>(), p->prod_b.as<int>());
         };
         S1Lanes lanes(ctx, p->opt_s1_serial != 0);
-        launch_rowsorts(ctx, p, lanes, counts, mt, bits_tc, force64);
+        launch_rowsorts(ctx, p, lanes, counts, mt, bits_tc, force64, nsegs);
         if (xl_local) {
             lanes.on(3);
             xl_gather(1);

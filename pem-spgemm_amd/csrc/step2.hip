@@ -500,7 +500,7 @@ pem_status pem::step2_impl(pem_ctx *ctx, pem_cplan *p)
                                              {&p->c_vals, (size_t)A->value_bytes * ((size_t)nnzc + 1)}}));
             PEM_TRY(p->s3_chunk_tile.reserve(sizeof(int) * ((size_t)nnzc / S3_CHUNK + 4)));
             WarmCheck wc = {};
-            if (p->warm_pass) wc = WarmCheck{1, p->w_P, p->w_Pall, p->w_TC, p->w_nnz, p->w_nxl, {p->w_counts[0], p->w_counts[1], p->w_counts[2], p->w_counts[3], p->w_counts[4]}, nullptr};
+            if (p->warm_pass) wc = WarmCheck{1, p->w_P, p->w_Pall, p->w_TC, p->w_nnz, p->w_nxl, {p->w_counts[0], p->w_counts[1], p->w_counts[2], p->w_counts[3], p->w_counts[4]}, p->w_nsegs, nullptr};
             p->verify_folded = p->warm_pass;
             // s2_offsets_kernel's checking thread is the last writer of a flag in the pass: it leaves all of them in host memory
             if (p->warm_pass && decode && ctx->h_flags_dev) {
