@@ -177,8 +177,9 @@ typedef enum {
                                        byte offsets on scalar bases while every array of the product is < 4 GiB)                     */
     PEM_OPT_S3_MARK = 13,           /* 1 (default; pruned plans): entry -> tile lookup by LDS marks + one ballot; 0: six-step shuffle search */
     PEM_OPT_S3_XCD = 14,            /* 1 (default): step 3's entry-per-lane kernels give XCD x the x-th contiguous eighth of C; 0: round-robin */
-    PEM_OPT_S1_SEGMENTS = 15,       /* 1 (default): tile rows above the 2048-key bin are sorted in column-range segments, one workgroup per
-                                       segment; 0: one workgroup per row (the 8192- and 32768-key bins)                              */
+    PEM_OPT_S1_SEGMENTS = 15,       /* 0 (default): one workgroup per tile row above the 8192-key bin (the 32768-key bin); 1: such rows are
+                                       sorted in column-range segments, one workgroup per segment -- pays where a plan holds a handful
+                                       of them (webbase-1M's directory rows in a 1/8 row block), costs where it holds hundreds          */
     PEM_OPT_S3_DECODE = 9           /* 1 (default): on plans with < 2 pairs per C tile step 3 reads (row, column) off the C masks and
                                        Ctiles_rowColIdx is materialised on demand; 0: step 2 writes it on every pass               */
 } pem_option;

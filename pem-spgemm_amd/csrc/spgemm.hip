@@ -84,7 +84,7 @@ extern "C" pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const p
     p->opt_s3_xcd = !env_is("PEM_S3_XCD", "0");
     p->opt_idx64 = env_is("PEM_S3_IDX64", "1");
     p->opt_mark = !env_is("PEM_S3_MARK", "0");
-    p->opt_s1_segments = !env_is("PEM_S1_SEGMENTS", "0");
+    p->opt_s1_segments = env_is("PEM_S1_SEGMENTS", "1");
     {
         const char *e = getenv("PEM_S3_EPW");
         p->opt_epw = e ? atoi(e) : 0;

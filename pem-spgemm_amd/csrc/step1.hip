@@ -471,10 +471,10 @@ __global__ void __launch_bounds__(256) s1_rowclass_kernel(const int *__restrict_
         else if (nl <= S1_CAP2 && np <= S1_PC2) bin = 2;
         else if (nl <= S1_CAP3 && np <= S1_PC3) bin = 3;
         else if (nl <= cap4 && np <= S1_PC3) bin = 4;
-        // rows above the 2048-key bin: column-range segments, one workgroup each (list 3 holds the rows, seg_list the segments)
-        if (seg_on && bin >= 3) bin = (nl <= S1_XLL_MAX && np <= S1_PC2) ? 3 : 5;
+        // rows above the 8192-key bin: column-range segments, one workgroup each (list 4 holds the rows, seg_list the segments)
+        if (seg_on && bin >= 4) bin = (nl <= S1_XLL_MAX && np <= S1_PC2) ? 4 : 5;
         if (nl > xlcap) bin = 5;                                 // test hook: rows above xlcap live products take the oversized-row path
-        if (seg_on && bin == 3) {
+        if (seg_on && bin == 4) {
             const int G = (nl + S1_SEG_T - 1) / S1_SEG_T;
             const int s0 = atomicAdd(&bin_count[BC_SEGS], G);
             for (int g = 0; g < G; ++g) seg_list[s0 + g] = make_int2(i, g | (G << 16));
@@ -969,14 +969,18 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
     }
 }
 
-// Big rows in column-range segments.  A row of more than 2048 live products sorted by ONE workgroup is a serial chain of tens of
-// microseconds (a directory page of webbase-1M: 11 k keys, 55 us; the round-2 stand-in has a thousand rows of 2-18 k keys) on a
-// chip that runs hundreds of workgroups -- so the row is cut into G = ceil(nl / 1024) ranges of tile columns and every range gets a
+// Big rows in column-range segments.  A row of more than 8192 live products sorted by ONE workgroup is a serial chain of 50-300
+// microseconds (a directory page of webbase-1M: 11 k keys, 55 us; the round-2 stand-in has a hundred rows of 8-18 k keys) on a chip
+// that runs hundreds of workgroups -- so the row is cut into G = ceil(nl / 1024) ranges of tile columns and every range gets a
 // workgroup of its own: it reads ALL the row's keys (coalesced, a few tens of KB from L2), keeps those whose tile column lies in its
 // range, in list order, and counts the keys of smaller columns -- which is where its pairs start in the row's output, no other
 // segment needed -- then sorts its keys like the 2048-key bin and emits.  The first pair of a segment opens a C tile (its column is
 // new), so the marks and counts that step 2 indexes C tiles by need nothing from the other segments either; the row's tile count is
-// summed by atomics.  Ranges are cut evenly over B's tile columns; one that holds more than 2048 keys is halved until it fits, a
+// summed by atomics.  (Rows of 2049-8192 keys keep their one workgroup: cut up as well, the thousand such rows of the round-2
+// stand-in -- every segment reads its whole row -- took 560 us where the 8192-key bin takes 300.)
+// Measured (round 4): webbase-1M, five rows above 8192 keys: the segments take 30 us where the 32768-key bin takes 57, the step
+// 8 us less (the other bins then set its length); the round-2 stand-in, 104 such rows: step 1 0.61 ms against 0.50 -- 1 300
+// workgroups each reading a 12 k-key row.  So the option (PEM_OPT_S1_SEGMENTS) is OFF by default.  Ranges are cut evenly over B's tile columns; one that holds more than 2048 keys is halved until it fits, a
 // single column with more than 2048 keys (a C tile of that many pairs) is emitted as it stands -- one column needs no sort.
 template <typename KeyT>
 __global__ void __launch_bounds__(1024) s1_rowseg_kernel(const int2 *__restrict__ seg_list, int nsegs, const int *__restrict__ a_tile_rowptr, int tr_lo,
@@ -1493,9 +1497,9 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
 // behind the row classification and joined before the row-count scan.  Four, because the runtime feeds four hardware queues: a
 // fifth stream shares a queue with one of the others, and in round 4's first cut the one-key-per-lane kernel (62 k waves, the
 // bulk of the work) landed behind the 32768-key bin (five workgroups, 61 us) on the main stream's queue.  The plan, by what
-// each kernel takes alone on webbase-1M:   main: tiny rows (30 us)   aux 0: the big rows' segments (34)   aux 1: 512-key bin (21)
-//                                          aux 2: 2048-key bin (28), then the oversized rows
-// (PEM_OPT_S1_SEGMENTS = 0:  main: tiny rows, then the 512-key bin   aux 0: 32768-key bin (61)   aux 1: 8192-key bin (35)   aux 2: as above)
+// each kernel takes alone on webbase-1M:   main: tiny rows (30 us)   aux 0: the segments of the rows above 8192 keys, then the 512-key bin (21)
+//                                          aux 1: 8192-key bin (35)  aux 2: 2048-key bin (28), then the oversized rows
+// (PEM_OPT_S1_SEGMENTS = 0:  main: tiny rows, then the 512-key bin   aux 0: 32768-key bin (61)   aux 1, aux 2: as above)
 struct S1Lanes {
     pem_ctx *ctx;
     hipStream_t main_stream;
@@ -1542,7 +1546,7 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
                              THREADS, PEM_ROWSORT_ARGS(BIN, QB));                                                                        \
     } while (0)
     if (p->opt_s1_segments) {
-        if (nsegs > 0) {                   // rows above the 2048-key bin, one workgroup per column-range segment
+        if (nsegs > 0) {                   // rows above the 8192-key bin, one workgroup per column-range segment
             lanes.on(1);
             if (bits_tc + S1_QB2 <= 32 && !force64)
                 PEM_LAUNCH_NAMED(ctx, "s1_rowseg_kernel", (s1_rowseg_kernel<uint32_t>), nsegs, 1024, p->seg_list.as<int2>(), nsegs, A->tile_rowptr.as<int>(),
@@ -1555,8 +1559,7 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
                                  p->live_ab.as<int2>(), p->B->tile_cols, p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->pair_col.as<int>(),
                                  p->blk_heads.as<int>(), p->c_tile_rowptr.as<int>());
         }
-    } else {
-    if (counts[4] > 0) {                   // (only populated where 32-bit keys hold a 15-bit index: see the row classification's cap4)
+    } else if (counts[4] > 0) {            // (only populated where 32-bit keys hold a 15-bit index: see the row classification's cap4)
         lanes.on(1);
         PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<32768>", (s1_rowsort_kernel<uint32_t, S1_CAP4, S1_QB4, 1024>), counts[4], 1024,
                          PEM_ROWSORT_ARGS(4, S1_QB4));
@@ -1564,7 +1567,6 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
     if (counts[3] > 0) {
         lanes.on(2);
         PEM_ROWSORT(3, 8192, S1_QB3, 1024);
-    }
     }
     if (counts[2] > 0) {
         lanes.on(3);
@@ -1577,7 +1579,7 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
                    p->blk_heads.as<int>(), p->c_tile_rowptr.as<int>());
     }
     if (counts[1] > 0) {
-        lanes.on(p->opt_s1_segments ? 2 : 0);   // (with the big rows in segments the second auxiliary stream is free: every bin has a queue of its own)
+        lanes.on(p->opt_s1_segments ? 1 : 0);   // (behind the few segments of the few rows above 8192 keys, or behind the tiny rows)
         PEM_ROWSORT(1, 512, S1_QB1, 64);
     }
     lanes.on(0);
@@ -1645,8 +1647,8 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
         p->group_nnz_cleared = true;
     }
     const int nblk_reset = p->warm_pass ? (int)(p->w_P / 256 + 1) : 0;   // (the buffer is in place since the plan's first pass)
-    // rows above the 2048-key bin are sorted in column-range segments (PEM_OPT_S1_SEGMENTS = 0: one workgroup per row, the 8192- and
-    // 32768-key bins); a row has at most nl / 1024 + 1 segments
+    // rows above the 8192-key bin are sorted in column-range segments (PEM_OPT_S1_SEGMENTS = 0: one workgroup per row, the
+    // 32768-key bin); a row has at most nl / 1024 + 1 segments
     const int seg_on = p->opt_s1_segments != 0;
     PEM_TRY(p->seg_list.reserve(sizeof(int2) * (ncap / S1_SEG_T + (size_t)mt + 16)));
     const int prune = p->opt_prune;

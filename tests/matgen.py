@@ -126,13 +126,13 @@ def step1_cases(rng):
     I, J = np.concatenate(I), np.concatenate(J)
     p = rng.permutation(len(I))
     out["xl_mixed_AAt"] = (6400, 3360, I[p].astype(np.int32), J[p].astype(np.int32), _vals(rng, len(I)), True)
-    # (iii) C tiles of more than 2048 PAIRS and big rows whose keys crowd a few tile columns: three rows of A (in tile rows 0, 1, 2
-    # of 4096) hold an entry in each of 2100 tile columns, so in A*A^T every one of the nine C tiles between them has 2100 pairs and
-    # each of the three tile rows 6300 live products in three tile columns out of 4096 -- the column-range segments of round 4 must
+    # (iii) C tiles of more than 2048 PAIRS and big rows whose keys crowd a few tile columns: five rows of A (in tile rows 0 .. 4
+    # of 4096) hold an entry in each of 2100 tile columns, so in A*A^T every one of the 25 C tiles between them has 2100 pairs and
+    # each of the five tile rows 10 500 live products in five tile columns out of 4096 -- the column-range segments of round 4 must
     # halve their ranges down to single columns and emit those unsorted
-    hub_rows = np.array([3, 20, 40])
+    hub_rows = np.array([3, 20, 40, 50, 70])
     I = np.repeat(hub_rows, 2100)
-    J = np.tile(16 * np.arange(2100) + 5, 3)
+    J = np.tile(16 * np.arange(2100) + 5, 5)
     extra_i, extra_j = rng.integers(0, 65536, 500), rng.integers(0, 33600, 500)
     key = rng.permutation(np.unique(np.concatenate([I.astype(np.int64) * 33600 + J, extra_i.astype(np.int64) * 33600 + extra_j])))
     out["hub_tile_2100_AAt"] = (65536, 33600, (key // 33600).astype(np.int32), (key % 33600).astype(np.int32), _vals(rng, len(key)), True)
