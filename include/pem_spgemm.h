@@ -155,33 +155,20 @@ pem_status pem_cplan_create(pem_ctx *ctx, const pem_tiled *A, const pem_tiled *B
                             int32_t tile_row_begin, int32_t tile_row_end, pem_cplan **out);
 pem_status pem_cplan_destroy(pem_ctx *ctx, pem_cplan *plan);
 
-/* Kernel variants and test hooks of a plan.  A new plan takes its defaults from the environment once, in
- * pem_cplan_create (PEM_PRUNE=0, PEM_STEP1=esc, PEM_WIDE=0, PEM_NO_WARM=1, PEM_S3_BAND=0, PEM_S1_FORCE_KEY64=1,
- * PEM_S1_XLCAP=n, PEM_EXPORT=rows); after that only pem_cplan_set_option changes them -- no entry point reads the
- * environment at call time.  Changing an option makes the next pass a full (size-reading) one. */
+/* Plan options.  A new plan takes its defaults from the environment once, in pem_cplan_create (PEM_PRUNE=0, PEM_STEP1=esc,
+ * PEM_WIDE=0, PEM_NO_WARM=1, PEM_S3_BAND=0, PEM_EXPORT=rows); after that only pem_cplan_set_option changes them -- no entry
+ * point reads the environment at call time.  Changing an option sends the plan back to the last step the option does not touch
+ * and makes the next pass a full (size-reading) one.  The values below are the public ones; the test hooks and tuning switches
+ * of the kernels (same entry points, further values of pem_option) are declared in pem_test.h. */
 typedef enum {
     PEM_OPT_PRUNE = 0,              /* 1 (default): drop tile products whose tiles cannot meet; 0: the reference's lists      */
-    PEM_OPT_STEP1_GLOBAL_SORT = 1,  /* 0 (default): row-local LDS sorts; 1: global expand + radix sort (the oversized-row path) */
+    PEM_OPT_STEP1_GLOBAL_SORT = 1,  /* 0 (default): row-local LDS sorts; 1: global expand + radix sort (A/B baseline of step 1) */
     PEM_OPT_WIDE = 2,               /* 1 (default): fused step 2 + entry-per-lane step 3; 0: 16-lanes-per-tile baseline kernels */
     PEM_OPT_WARM = 3,               /* 1 (default): repeat passes re-use the previous pass's sizes (device-verified); 0: read back */
     PEM_OPT_S3_BAND = 4,            /* 1 (default): many-pair C tiles of deep plans go to the wave-per-tile kernel              */
-    PEM_OPT_S1_FORCE_KEY64 = 5,     /* test hook: 64-bit sort keys whatever B's width                                          */
-    PEM_OPT_S1_XLCAP = 6,           /* test hook: tile rows with more live products take the global path (0: off)              */
     PEM_OPT_EXPORT_ROWS = 7,        /* 0 (default): balanced chunk export; 1: 16 lanes per tile row (A/B baseline)             */
-    PEM_OPT_S1_SERIAL = 8,          /* diagnostic: step 1's row bins one after the other instead of concurrently               */
-    PEM_OPT_S1_XL_GLOBAL = 10,      /* 0 (default): tile rows beyond the LDS bins are sorted one workgroup per row where their products
-                                       lie; 1: all of them through one global radix sort on (row, tile column) (rows above 2^18 live
-                                       products always)                                                                              */
-    PEM_OPT_S3_EPW = 11,            /* step 3: C entries per wave / 256 (0, default: 1, or 4 where C tiles hold 8+ entries on average) */
-    PEM_OPT_S3_IDX64 = 12,          /* test hook: the mask-decoding step 3 addresses with 64-bit indices whatever the sizes (default: 32-bit
-                                       byte offsets on scalar bases while every array of the product is < 4 GiB)                     */
-    PEM_OPT_S3_MARK = 13,           /* 1 (default; pruned plans): entry -> tile lookup by LDS marks + one ballot; 0: six-step shuffle search */
-    PEM_OPT_S3_XCD = 14,            /* 1 (default): step 3's entry-per-lane kernels give XCD x the x-th contiguous eighth of C; 0: round-robin */
-    PEM_OPT_S1_SEGMENTS = 15,       /* 0 (default): one workgroup per tile row above the 8192-key bin (the 32768-key bin); 1: such rows are
-                                       sorted in column-range segments, one workgroup per segment -- pays where a plan holds a handful
-                                       of them (webbase-1M's directory rows in a 1/8 row block), costs where it holds hundreds          */
-    PEM_OPT_S3_DECODE = 9           /* 1 (default): on plans with < 2 pairs per C tile step 3 reads (row, column) off the C masks and
-                                       Ctiles_rowColIdx is materialised on demand; 0: step 2 writes it on every pass               */
+    PEM_OPT__TEST_FIRST = 5,        /* (5, 6, 8-15: pem_test.h)                                                                 */
+    PEM_OPT__LAST = 15
 } pem_option;
 pem_status pem_cplan_set_option(pem_cplan *plan, pem_option which, int64_t value);
 pem_status pem_cplan_get_option(const pem_cplan *plan, pem_option which, int64_t *value);
@@ -271,15 +258,6 @@ pem_status pem_set_kernel_profiling(pem_ctx *ctx, int enabled);
 pem_status pem_reset_kernel_stats(pem_ctx *ctx);
 pem_status pem_kernel_stats_count(pem_ctx *ctx, int *n);
 pem_status pem_kernel_stats_get(pem_ctx *ctx, int idx, char *name, int name_cap, int64_t *calls, double *total_ms);
-
-/* ---- test hooks -------------------------------------------------------------------------- */
-/* The device exclusive scan (replaces thrust::exclusive_scan, spgemm.cu:1168, 1242, 1288, and NSPARSE/utils_cuda_scan.h)
- * on a caller's array: out[0..n] = exclusive prefix sums, out[n] = *total.  regime 0: chosen by n like the hot path;
- * 1: one block; 2: the single-launch chained scan (n <= 262144); 3: the three-launch scan.  in_place scans the device
- * copy in place (as the hot path does); stall_ticket >= 0 makes that block of the chained scan stall for ~0.1 ms before
- * it publishes, so every later block sits out a long wait. */
-pem_status pem_debug_scan_i32(pem_ctx *ctx, const int32_t *in, int64_t n, int regime, int in_place, int stall_ticket,
-                              int32_t *out, int64_t *total);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 #include "../../include/pem_spgemm.h"
+#include "../../include/pem_test.h"
 
 namespace pem {
 

@@ -150,7 +150,7 @@ extern "C" pem_status pem_cplan_get_info(const pem_cplan *p, pem_cplan_info *inf
 
 static int *plan_option_slot(pem_cplan *p, pem_option which)
 {
-    switch (which) {
+    switch ((int)which) {                              // (pem_test.h adds values to the enum's)
     case PEM_OPT_PRUNE: return &p->opt_prune;
     case PEM_OPT_STEP1_GLOBAL_SORT: return &p->opt_step1_esc;
     case PEM_OPT_WIDE: return &p->opt_wide;
@@ -189,7 +189,7 @@ extern "C" pem_status pem_cplan_set_option(pem_cplan *plan, pem_option which, in
     // (step 3 derives its tile lookup from PRUNE, step 2's output depends on DECODE, ...)
     // -- back to the last step the option does not touch
     int keep = 3;
-    switch (which) {
+    switch ((int)which) {
     case PEM_OPT_PRUNE: case PEM_OPT_STEP1_GLOBAL_SORT: case PEM_OPT_S1_FORCE_KEY64: case PEM_OPT_S1_XLCAP: case PEM_OPT_S1_XL_GLOBAL:
     case PEM_OPT_S1_SEGMENTS: keep = 0; break;
     case PEM_OPT_WIDE: case PEM_OPT_S3_DECODE: keep = 1; break;

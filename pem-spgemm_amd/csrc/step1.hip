@@ -1496,10 +1496,14 @@ static pem_status step1_esc_impl(pem_ctx *ctx, pem_cplan *p)
 // The row bins and the oversized-row chain run concurrently on FOUR streams -- the main one and three auxiliary ones, forked
 // behind the row classification and joined before the row-count scan.  Four, because the runtime feeds four hardware queues: a
 // fifth stream shares a queue with one of the others, and in round 4's first cut the one-key-per-lane kernel (62 k waves, the
-// bulk of the work) landed behind the 32768-key bin (five workgroups, 61 us) on the main stream's queue.  The plan, by what
-// each kernel takes alone on webbase-1M:   main: tiny rows (30 us)   aux 0: the segments of the rows above 8192 keys, then the 512-key bin (21)
-//                                          aux 1: 8192-key bin (35)  aux 2: 2048-key bin (28), then the oversized rows
-// (PEM_OPT_S1_SEGMENTS = 0:  main: tiny rows, then the 512-key bin   aux 0: 32768-key bin (61)   aux 1, aux 2: as above)
+// bulk of the work) landed behind the 32768-key bin (five workgroups, 57 us) on the main stream's queue.  The plan, by what
+// each kernel takes alone on webbase-1M:
+//     main: 32768-key bin (57 us; or its rows' segments, PEM_OPT_S1_SEGMENTS)     aux 0: tiny rows (33), then the 512-key bin (21)
+//     aux 1: 8192-key bin (38)                                                     aux 2: 2048-key bin (28), then the oversized rows
+// The 32768-key bin goes FIRST and on the main stream: a workgroup of it needs a CU's whole LDS, so it can only start on a CU that
+// holds no other LDS-using workgroup; dispatched the moment the row classification retires -- the forked streams get through their
+// event waits ~14 us later -- its workgroups are placed before the other bins' reach the CUs (behind them the hundred such rows of
+// the round-2 stand-in waited for CUs to drain: 340 us).
 struct S1Lanes {
     pem_ctx *ctx;
     hipStream_t main_stream;
@@ -1547,7 +1551,7 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
     } while (0)
     if (p->opt_s1_segments) {
         if (nsegs > 0) {                   // rows above the 8192-key bin, one workgroup per column-range segment
-            lanes.on(1);
+            lanes.on(0);
             if (bits_tc + S1_QB2 <= 32 && !force64)
                 PEM_LAUNCH_NAMED(ctx, "s1_rowseg_kernel", (s1_rowseg_kernel<uint32_t>), nsegs, 1024, p->seg_list.as<int2>(), nsegs, A->tile_rowptr.as<int>(),
                                  p->tr_lo, p->a_lo, p->aseg.as<int2>(), p->row_lbase.as<int>(), p->live_j.as<int>(), p->live_ab.as<int2>(),
@@ -1560,7 +1564,7 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
                                  p->blk_heads.as<int>(), p->c_tile_rowptr.as<int>());
         }
     } else if (counts[4] > 0) {            // (only populated where 32-bit keys hold a 15-bit index: see the row classification's cap4)
-        lanes.on(1);
+        lanes.on(0);
         PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<32768>", (s1_rowsort_kernel<uint32_t, S1_CAP4, S1_QB4, 1024>), counts[4], 1024,
                          PEM_ROWSORT_ARGS(4, S1_QB4));
     }
@@ -1573,13 +1577,13 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
         PEM_ROWSORT(2, 2048, S1_QB2, 256);
     }
     if (counts[0] > 0) {
-        lanes.on(0);
+        lanes.on(1);
         PEM_LAUNCH(ctx, s1_tiny_kernel, grid_for((size_t)counts[0] * 64, 256), 256, rl, counts[0], p->row_desc.as<int4>(), p->row_lbase.as<int>(),
                    p->live_j.as<int>(), p->live_ab.as<int2>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->pair_col.as<int>(),
                    p->blk_heads.as<int>(), p->c_tile_rowptr.as<int>());
     }
     if (counts[1] > 0) {
-        lanes.on(p->opt_s1_segments ? 1 : 0);   // (behind the few segments of the few rows above 8192 keys, or behind the tiny rows)
+        lanes.on(1);
         PEM_ROWSORT(1, 512, S1_QB1, 64);
     }
     lanes.on(0);

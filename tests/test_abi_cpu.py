@@ -18,8 +18,8 @@ def _declared(header):
 
 def test_hip_library_exports_every_declared_symbol(pkg):
     lib = pkg.lib()
-    declared = _declared("pem_spgemm.h")
-    assert len(declared) >= 28
+    declared = sorted(set(_declared("pem_spgemm.h") + _declared("pem_test.h")))   # (the test hooks live in the same library)
+    assert len(declared) >= 28 and "pem_debug_scan_i32" not in _declared("pem_spgemm.h")
     for sym in declared:
         assert hasattr(lib, sym), f"libpemspgemm_hip.so does not export {sym}"
     assert sorted(pkg.ABI_SYMBOLS) == declared
