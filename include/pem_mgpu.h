@@ -43,6 +43,25 @@ void pem_mgpu_rebase_rowptr(int n, const int64_t *nrows, const int32_t *const *s
 pem_status pem_mgpu_gather_csr(pem_mgpu *m, pem_cplan *const *plans, int root, int64_t *nrows, int64_t *nnz, int32_t *rowptr,
                                int32_t *colidx, double *vals, double *gather_ms);
 
+/* Row-block boundaries re-cut from MEASURED per-rank pass times (setup work of an N-GPU run, before anything is timed).
+ * weights[0 .. mt): pem_tile_row_weights; bounds[0 .. nparts]: the cut that was timed; ms[p]: rank p's time per pass on its
+ * block.  Model: a rank's pass costs fixed_ms (launch structure, latency chains: what no row carries) plus its rows' weights at
+ * the rate measured on that rank; rows keep the rate of the part they were timed in, and the new cut gives every rank the same
+ * share of the summed cost.  Host arithmetic (tested on CPU against the Python harness' multigpu.recut_bounds). */
+pem_status pem_mgpu_recut_bounds(int nparts, int mt, const double *weights, const int32_t *bounds, const double *ms, double fixed_ms,
+                                 int32_t *out);
+
+/* One pass of the whole product with the exchange overlapped: every rank's row block is cut into `nchunks` chunks
+ * (plans[rank * nchunks + c], tile rows abutting in that order; pem_split_tile_rows over n * nchunks parts balances them),
+ * one host thread per device computes its chunks in order, and chunk c's CSR export travels to `root` over RCCL -- straight
+ * into its place in the root's assembled arrays -- while chunk c + 1 computes.  The first call on a set of plans runs them once
+ * to learn the chunks' sizes (the root posts its receives by size); later calls are the overlapped pass alone.
+ * pass_ms: from the moment all ranks start to the moment the last one has finished steps 1-3 of its last chunk;
+ * tail_ms: from there until every transfer has landed (the part of the exchange the compute did not hide).
+ * rowptr == NULL: the pass runs and the assembled C stays on the root device (sizes in *nrows / *nnz). */
+pem_status pem_mgpu_spgemm_gather_chunked(pem_mgpu *m, pem_cplan *const *plans, int nchunks, int root, int64_t *nrows, int64_t *nnz,
+                                          int32_t *rowptr, int32_t *colidx, double *vals, double *pass_ms, double *tail_ms);
+
 #ifdef __cplusplus
 }
 #endif

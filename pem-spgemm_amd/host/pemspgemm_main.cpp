@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -72,11 +73,17 @@ struct MultiResult {
     std::vector<int32_t> rowptr, colidx;
     std::vector<double> vals;
     bool gathered = false;
+    // the measured re-cut of the row split, and the chunked pass with the gather overlapped (libpemmgpu.so)
+    int tune_rounds = 0;
+    double tune_first_max = 0, tune_best_max = 0;
+    std::vector<int32_t> bounds;
+    int chunks = 0;
+    double chunk_pass_ms = 0, chunk_tail_ms = 0;
 };
 }   // namespace
 
 static int run_multi(int ngpu, const pem_coo &ca, const pem_coo *cb, bool aat, bool want_c, int WARMUP, int REPEAT, bool fastest,
-                     std::chrono::high_resolution_clock::time_point conv_start, MultiResult &res)
+                     std::chrono::high_resolution_clock::time_point conv_start, MultiResult &res, bool tune_split, int nchunks)
 {
     std::vector<int> devs((size_t)ngpu);
     for (int g = 0; g < ngpu; ++g) devs[(size_t)g] = g;
@@ -93,6 +100,10 @@ static int run_multi(int ngpu, const pem_coo &ca, const pem_coo *cb, bool aat, b
     std::atomic<int> failed{0};
     std::vector<std::string> errs((size_t)ngpu);
     Barrier bar(ngpu);
+    std::vector<int32_t> cur((size_t)ngpu + 1, 0);          // the cut being timed (split tuning)
+    std::vector<double> weights, tune_ms((size_t)ngpu, 0.0);
+    int mt_all = 0;
+    bool tune_done = false;
     const pem_coo &b_src = cb ? *cb : ca;
     auto worker = [&](int g) {
         pem_ctx *ctx = pem_mgpu_ctx(m, g);
@@ -120,6 +131,11 @@ static int run_multi(int ngpu, const pem_coo &ca, const pem_coo *cb, bool aat, b
                 failed = 1;
             } else if (pem_split_tile_rows(ctx, A[0], B[0], ngpu, bounds.data()) != PEM_OK || pem_flop_count(ctx, A[0], B[0], &res.flop) != PEM_OK) {
                 fail("row split");
+            } else {
+                mt_all = ia.tile_rows;
+                weights.resize((size_t)mt_all);
+                if (tune_split && ngpu > 1 && pem_tile_row_weights(ctx, A[0], B[0], weights.data()) != PEM_OK) fail("tile-row weights");
+                cur = bounds;
             }
             res.rows = ia.rows;
             res.cols_b = ib.cols;
@@ -128,6 +144,50 @@ static int run_multi(int ngpu, const pem_coo &ca, const pem_coo *cb, bool aat, b
             res.conv_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - conv_start).count();
         }
         bar.wait();
+        // Measure-and-recut of the row split (setup, before anything is timed; the Python harness' multigpu.tune_row_bounds): every
+        // rank times twenty repeat passes of its block as a replayed graph, rank 0 re-cuts the blocks from the times
+        // (pem_mgpu_recut_bounds) so that ranks whose rows cost more per unit of weight get fewer of them; up to three rounds, and a
+        // later cut is only kept if it beats the first by 3 % (pass times move by that much from run to run).
+        if (tune_split && ngpu > 1) {
+            for (int rnd = 0; rnd <= 3 && !failed; ++rnd) {
+                pem_cplan *tp = nullptr;
+                if (pem_cplan_create(ctx, A[(size_t)g], B[(size_t)g], cur[(size_t)g], cur[(size_t)g + 1], &tp) != PEM_OK) fail("plan (split tuning)");
+                pem_set_graph_replay(ctx, 1);
+                for (int k = 0; k < 3 && !failed; ++k)
+                    if (pem_spgemm(ctx, tp) != PEM_OK) fail("pem_spgemm (split tuning)");
+                bar.wait();
+                const auto t0 = std::chrono::high_resolution_clock::now();
+                for (int k = 0; k < 20 && !failed; ++k)
+                    if (pem_spgemm(ctx, tp) != PEM_OK) fail("pem_spgemm (split tuning)");
+                tune_ms[(size_t)g] = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count() / 20.0;
+                pem_set_graph_replay(ctx, 0);
+                if (tp) pem_cplan_destroy(ctx, tp);
+                bar.wait();
+                if (g == 0 && !failed) {
+                    const double mx = *std::max_element(tune_ms.begin(), tune_ms.end()), mn = *std::min_element(tune_ms.begin(), tune_ms.end());
+                    double mean = 0;
+                    for (double x : tune_ms) mean += x / (double)ngpu;
+                    if (rnd == 0) {
+                        res.tune_first_max = res.tune_best_max = mx;
+                        bounds = cur;
+                    } else if (mx < res.tune_best_max && mx < 0.97 * res.tune_first_max) {
+                        res.tune_best_max = mx;
+                        bounds = cur;
+                    }
+                    res.tune_rounds = rnd + 1;
+                    tune_done = rnd == 3 || mx <= 1.04 * mean;
+                    if (!tune_done) {
+                        std::vector<int32_t> nxt((size_t)ngpu + 1);
+                        if (pem_mgpu_recut_bounds(ngpu, mt_all, weights.data(), cur.data(), tune_ms.data(), (rnd == 0 ? 0.6 : 0.5) * mn, nxt.data()) != PEM_OK)
+                            tune_done = true;
+                        else
+                            cur = nxt;
+                    }
+                }
+                bar.wait();
+                if (tune_done) break;
+            }
+        }
         if (!failed && pem_cplan_create(ctx, A[(size_t)g], B[(size_t)g], bounds[(size_t)g], bounds[(size_t)g + 1], &plan[(size_t)g]) != PEM_OK)
             fail("plan");
         for (int n = 0; n < WARMUP + REPEAT; ++n) {
@@ -200,6 +260,43 @@ static int run_multi(int ngpu, const pem_coo &ca, const pem_coo *cb, bool aat, b
             }
         }
     }
+    res.bounds = bounds;
+    // the same product as ONE call with the exchange overlapped: every rank's block in `nchunks` chunks, chunk c travelling to
+    // device 0 while chunk c + 1 computes (pem_mgpu_spgemm_gather_chunked; the Python harness' ChunkedRowBlock)
+    if (rc == 0 && nchunks != 0 && res.nnz_c > 0) {
+        int K = nchunks;
+        if (K < 0) {                                         // from the bytes one rank sends: ~48 MB of CSR per chunk, 2 .. 8
+            const double per_rank = 12.0 * (double)res.nnz_c / (double)ngpu;
+            K = (int)std::max(2.0, std::min(8.0, std::ceil(per_rank / (48.0 * 1048576.0))));
+        }
+        std::vector<int32_t> cb_((size_t)ngpu * (size_t)K + 1, 0);
+        std::vector<pem_cplan *> cp((size_t)ngpu * (size_t)K, nullptr);
+        bool ok = pem_split_tile_rows(pem_mgpu_ctx(m, 0), A[0], B[0], ngpu * K, cb_.data()) == PEM_OK;
+        for (int s = 0; ok && s < ngpu * K; ++s)
+            ok = pem_cplan_create(pem_mgpu_ctx(m, s / K), A[(size_t)(s / K)], B[(size_t)(s / K)], cb_[(size_t)s], cb_[(size_t)s + 1], &cp[(size_t)s]) == PEM_OK;
+        int64_t nr = 0, nz = 0;
+        double pass = 0, tail = 0, sp = 0, st = 0;
+        if (ok) ok = pem_mgpu_spgemm_gather_chunked(m, cp.data(), K, 0, &nr, &nz, nullptr, nullptr, nullptr, &pass, &tail) == PEM_OK;   // sizes, warm plans
+        for (int n = 0; ok && n < REPEAT; ++n) {
+            ok = pem_mgpu_spgemm_gather_chunked(m, cp.data(), K, 0, &nr, &nz, nullptr, nullptr, nullptr, &pass, &tail) == PEM_OK;
+            sp += pass / REPEAT;
+            st += tail / REPEAT;
+        }
+        if (ok && nz != res.nnz_c) {
+            fprintf(stderr, "pemspgemm: chunked pass: %lld entries, the row-block pass had %lld\n", (long long)nz, (long long)res.nnz_c);
+            ok = false;
+        }
+        if (ok) {
+            res.chunks = K;
+            res.chunk_pass_ms = sp;
+            res.chunk_tail_ms = st;
+        } else {
+            fprintf(stderr, "pemspgemm: chunked pass: %s\n", pem_last_error());
+            rc = 2;
+        }
+        for (int s = 0; s < ngpu * K; ++s)
+            if (cp[(size_t)s]) pem_cplan_destroy(pem_mgpu_ctx(m, s / K), cp[(size_t)s]);
+    }
     for (int g = 0; g < ngpu; ++g) {
         pem_ctx *ctx = pem_mgpu_ctx(m, g);
         if (plan[(size_t)g]) pem_cplan_destroy(ctx, plan[(size_t)g]);
@@ -231,14 +328,17 @@ int main(int argc, char *argv[])
     // `--cache <dir>` keeps each tiling as <dir>/<stem>.<A|AT>.pemtile and, while the .mtx is unchanged
     // (size + mtime), loads it instead of parsing and converting.
     // `--fp32` computes in float: the values are rounded once at conversion, step 3 runs one fmaf per product.
-    // `--gpus N`: N tile-row blocks of A on N devices, C gathered to device 0 over RCCL (see run_multi).
+    // `--gpus N`: N tile-row blocks of A on N devices, C gathered to device 0 over RCCL (see run_multi); the blocks are
+    // re-cut from measured pass times first (`--no-tune-split` keeps the product-balanced cut), and the product is also run as
+    // `--chunks K` chunks per rank with the gather overlapped (default: K from C's size; 0: off).
     // `--standin NAME [--scale S]`: the seeded C++ stand-in generator takes the place of the file (no SuiteSparse
     // file exists offline); NAME then stands where the path stood, and the remaining positional arguments keep their meaning.
     const char *b_path = nullptr, *out_path = nullptr, *cache_dir = nullptr, *standin = nullptr;
     static std::string standin_path;
     static std::vector<char *> argv_store;
-    bool fp32 = false;
+    bool fp32 = false, tune_split = true;
     int ngpu = 0;   // 0: the reference's single-device path
+    int nchunks = -1;   // --gpus: chunks per rank of the overlapped pass (-1: from C's size, 0: off)
     {
         int w = 1;
         for (int r = 1; r < argc; ++r) {
@@ -249,6 +349,8 @@ int main(int argc, char *argv[])
             else if (!strcmp(argv[r], "--out") && r + 1 < argc) out_path = argv[++r];
             else if (!strcmp(argv[r], "--cache") && r + 1 < argc) cache_dir = argv[++r];
             else if (!strcmp(argv[r], "--fp32")) fp32 = true;
+            else if (!strcmp(argv[r], "--no-tune-split")) tune_split = false;
+            else if (!strcmp(argv[r], "--chunks") && r + 1 < argc) nchunks = atoi(argv[++r]);
             else argv[w++] = argv[r];
         }
         argc = w;
@@ -286,7 +388,7 @@ int main(int argc, char *argv[])
         }
         printf("MATRIX A\nfilepath: %s\nRows: %d\nCols: %d\nNnz: %lld\n", argv[1], ca.rows, ca.cols, (long long)ca.nnz);
         MultiResult mr;
-        int rc = run_multi(ngpu, ca, b_path ? &cb : nullptr, aat, save || out_path, WARMUP, REPEAT, fastest, conv_start_m, mr);
+        int rc = run_multi(ngpu, ca, b_path ? &cb : nullptr, aat, save || out_path, WARMUP, REPEAT, fastest, conv_start_m, mr, tune_split, nchunks);
         if (rc == 0) {
             const double kernel = mr.step1 + mr.step2 + mr.step3, malloc_ms = mr.total - kernel;
             const double gflops = mr.total > 0 ? (double)mr.flop * 2.0 / (mr.total * 1e6) : 0.0;
@@ -301,6 +403,16 @@ int main(int argc, char *argv[])
             printf("pemSpGEMM took %.2fms ----- GFlops: %.2f\nKernel time %.2fms\nmalloc time %.2fms\n", mr.total, gflops, kernel, malloc_ms);
             printf("first pass (allocations + size read-backs) %.2fms\n", mr.cold);
             if (mr.gathered) printf("gather of C to GPU 0 over RCCL took %.2fms ----- GFlops with it: %.2f\n", mr.gather_ms, gflops_x);
+            if (mr.tune_rounds > 0)
+                printf("row split re-cut from measured pass times: %d round(s), slowest rank %.3fms -> %.3fms\n", mr.tune_rounds, mr.tune_first_max,
+                       mr.tune_best_max);
+            printf("tile-row blocks:");
+            for (size_t g = 0; g + 1 < mr.bounds.size(); ++g) printf(" [%d,%d)", mr.bounds[g], mr.bounds[g + 1]);
+            printf("\n");
+            if (mr.chunks > 0)
+                printf("%d chunks per rank, gather overlapped: compute %.2fms + transfers still in flight %.2fms ----- GFlops with the exchange: %.2f\n",
+                       mr.chunks, mr.chunk_pass_ms, mr.chunk_tail_ms,
+                       mr.chunk_pass_ms + mr.chunk_tail_ms > 0 ? (double)mr.flop * 2.0 / ((mr.chunk_pass_ms + mr.chunk_tail_ms) * 1e6) : 0.0);
             printf("Flop count: %llu\n\nC tiles: %lld\nC nnz: %lld\nCompression ratio %.2f\n", (unsigned long long)mr.flop, (long long)mr.ntiles_c,
                    (long long)mr.nnz_c, ratio);
             const double b_alg = 12.0 * ((double)ca.nnz + (double)(b_path ? cb.nnz : ca.nnz) + (double)mr.nnz_c) + 4.0 * 3.0 * ((double)ca.rows + 1);
@@ -313,8 +425,11 @@ int main(int argc, char *argv[])
             pem_csv_record rec = {stem.c_str(), mr.flop, mr.nnz_c, ratio, mr.a_conv_kernel_ms, mr.b_conv_kernel_ms, mr.conv_ms,
                                   mr.step1, mr.step2, mr.step3, mr.total, kernel, malloc_ms, gflops};
             char extra[320];
-            snprintf(extra, sizeof extra, "%d,%.0f,%.4f,%.4f,%lld,%lld,%.2f,%.2f", ngpu, b_alg, frac_kernel, frac_total, (long long)mr.ntiles_c,
-                     (long long)mr.npairs, mr.cold, mr.gather_ms);
+            // columns 15..: gpus, B_alg, roofline fraction (kernel, total), C tiles, live pairs, first-pass ms, gather ms (sequential),
+            // chunks per rank, chunked pass ms, transfers still in flight after it ms, split-tuning rounds, slowest rank before / after (ms)
+            snprintf(extra, sizeof extra, "%d,%.0f,%.4f,%.4f,%lld,%lld,%.2f,%.2f,%d,%.2f,%.2f,%d,%.3f,%.3f", ngpu, b_alg, frac_kernel, frac_total,
+                     (long long)mr.ntiles_c, (long long)mr.npairs, mr.cold, mr.gather_ms, mr.chunks, mr.chunk_pass_ms, mr.chunk_tail_ms, mr.tune_rounds,
+                     mr.tune_first_max, mr.tune_best_max);
             const char *csv = getenv("PEM_CSV") ? getenv("PEM_CSV") : "./pemspgemm_benchmark_result.csv";
             if (pem_csv_append(csv, &rec, extra) != 0) fprintf(stderr, "pemspgemm: %s\n", pem_host_last_error());
             if (!save) {

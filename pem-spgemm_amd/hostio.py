@@ -27,7 +27,7 @@ class CsvRecord(C.Structure):
 
 
 MGPU_SYMBOLS = ["pem_mgpu_create", "pem_mgpu_destroy", "pem_mgpu_size", "pem_mgpu_ctx", "pem_mgpu_slice_offsets", "pem_mgpu_rebase_rowptr",
-                "pem_mgpu_gather_csr"]
+                "pem_mgpu_gather_csr", "pem_mgpu_recut_bounds", "pem_mgpu_spgemm_gather_chunked"]
 
 _lib = None
 _mgpu = None
@@ -42,6 +42,82 @@ def mgpu_lib():
         C.CDLL(os.path.join(_HERE, "libpemspgemm_hip.so"), mode=C.RTLD_GLOBAL)
         _mgpu = C.CDLL(MGPU_LIB_PATH)
     return _mgpu
+
+
+def mgpu_recut_bounds(weights, bounds, ms, fixed_ms=0.0):
+    """pem_mgpu_recut_bounds: row-block boundaries re-cut from measured per-rank pass times (host arithmetic of the C++ `--gpus N` path)"""
+    w = np.ascontiguousarray(weights, np.float64)
+    b = np.ascontiguousarray(bounds, np.int32)
+    t = np.ascontiguousarray(ms, np.float64)
+    out = np.zeros(len(b), np.int32)
+    pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    st = mgpu_lib().pem_mgpu_recut_bounds(len(b) - 1, len(w), w.ctypes.data_as(pd), b.ctypes.data_as(pi), t.ctypes.data_as(pd), C.c_double(fixed_ms),
+                                          out.ctypes.data_as(pi))
+    if st != 0:
+        raise ValueError(f"pem_mgpu_recut_bounds: status {st}")
+    return out
+
+
+def mgpu_chunked_pass(devices, rows, cols, I, J, V, nchunks, transpose_b=False):
+    """One product through libpemmgpu.so's chunked, overlapped pass (pem_mgpu_spgemm_gather_chunked) on the listed devices:
+    A = B = the COO given (B transposed if asked), every rank's row block in `nchunks` chunks.  Returns (rowptr, colidx, vals,
+    pass_ms, tail_ms) of the assembled C."""
+    L = mgpu_lib()
+    H = C.CDLL(os.path.join(_HERE, "libpemspgemm_hip.so"), mode=C.RTLD_GLOBAL)
+    L.pem_mgpu_ctx.restype = C.c_void_p
+    n = len(devices)
+    m = C.c_void_p()
+    devs = (C.c_int * n)(*devices)
+    if L.pem_mgpu_create(n, devs, C.byref(m)) != 0:
+        raise RuntimeError("pem_mgpu_create failed")
+    I = np.ascontiguousarray(I, np.int32)
+    J = np.ascontiguousarray(J, np.int32)
+    V = np.ascontiguousarray(V, np.float64)
+    pi, pd = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    As, Bs, plans = [], [], []
+    try:
+        for g in range(n):
+            ctx = C.c_void_p(L.pem_mgpu_ctx(m, g))
+            a = C.c_void_p()
+            assert H.pem_tiled_from_coo(ctx, rows, cols, C.c_int64(len(I)), I.ctypes.data_as(pi), J.ctypes.data_as(pi), V.ctypes.data_as(pd), 0, C.byref(a)) == 0
+            As.append(a)
+            if transpose_b:
+                b = C.c_void_p()
+                assert H.pem_tiled_from_coo(ctx, rows, cols, C.c_int64(len(I)), I.ctypes.data_as(pi), J.ctypes.data_as(pi), V.ctypes.data_as(pd), 1, C.byref(b)) == 0
+                Bs.append(b)
+            else:
+                Bs.append(a)
+        S = n * nchunks
+        bounds = (C.c_int32 * (S + 1))()
+        assert H.pem_split_tile_rows(C.c_void_p(L.pem_mgpu_ctx(m, 0)), As[0], Bs[0], S, bounds) == 0
+        for s in range(S):
+            p = C.c_void_p()
+            assert H.pem_cplan_create(C.c_void_p(L.pem_mgpu_ctx(m, s // nchunks)), As[s // nchunks], Bs[s // nchunks], bounds[s], bounds[s + 1], C.byref(p)) == 0
+            plans.append(p)
+        parr = (C.c_void_p * S)(*[p.value for p in plans])
+        nr, nz, pass_ms, tail_ms = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
+        st = L.pem_mgpu_spgemm_gather_chunked(m, parr, nchunks, 0, C.byref(nr), C.byref(nz), None, None, None, C.byref(pass_ms), C.byref(tail_ms))
+        if st != 0:
+            H.pem_last_error.restype = C.c_char_p
+            raise RuntimeError(H.pem_last_error().decode(errors="replace"))
+        rp = np.zeros(nr.value + 1, np.int32)
+        ci = np.zeros(nz.value, np.int32)
+        v = np.zeros(nz.value, np.float64)
+        st = L.pem_mgpu_spgemm_gather_chunked(m, parr, nchunks, 0, C.byref(nr), C.byref(nz), rp.ctypes.data_as(pi), ci.ctypes.data_as(pi), v.ctypes.data_as(pd),
+                                              C.byref(pass_ms), C.byref(tail_ms))
+        if st != 0:
+            H.pem_last_error.restype = C.c_char_p
+            raise RuntimeError(H.pem_last_error().decode(errors="replace"))
+        return rp, ci, v, pass_ms.value, tail_ms.value
+    finally:
+        for s, p in enumerate(plans):
+            H.pem_cplan_destroy(C.c_void_p(L.pem_mgpu_ctx(m, s // nchunks)), p)
+        for g in range(len(As)):
+            ctx = C.c_void_p(L.pem_mgpu_ctx(m, g))
+            if Bs[g].value != As[g].value:
+                H.pem_tiled_destroy(ctx, Bs[g])
+            H.pem_tiled_destroy(ctx, As[g])
+        L.pem_mgpu_destroy(m)
 
 
 def mgpu_assemble_rowptr(slice_rowptrs, nnzs):

@@ -56,6 +56,17 @@ def test_mgpu_library_exports_and_assembles_row_pointers(pkg):
         assert np.array_equal(rowptr, want)
         assert np.array_equal(row_off, np.concatenate([[0], np.cumsum([len(l) for l in lens])]))
         assert np.array_equal(nnz_off, np.concatenate([[0], np.cumsum([int(l.sum()) for l in lens])]))
+    # the re-cut of the row split from measured times: the C++ host's arithmetic against the Python harness'
+    mg = importlib.import_module("pem_spgemm_amd.multigpu")
+    for nparts in (1, 2, 3, 8):
+        mt = int(rng.integers(nparts, 400))
+        w = rng.uniform(0.5, 50.0, mt)
+        w[rng.integers(0, mt, 3)] = 5000.0                                                  # a few hub rows
+        cuts = np.sort(rng.integers(0, mt + 1, nparts - 1))
+        b = np.concatenate([[0], cuts, [mt]]).astype(np.int32)
+        ms = rng.uniform(0.2, 0.4, nparts)
+        for fixed in (0.0, 0.6 * ms.min()):
+            assert np.array_equal(hostio.mgpu_recut_bounds(w, b, ms, fixed), mg.recut_bounds(w, b, ms, fixed=fixed)), (nparts, fixed)
     if not __import__("torch").cuda.is_available():
         m = C.c_void_p()
         devs = (C.c_int * 1)(0)

@@ -220,7 +220,11 @@ def test_cli_gpus_path_gathers_through_rccl_library(pkg, oracle, standins, tmp_p
     C.sort_indices()
     assert np.array_equal(C.indptr, rp) and np.array_equal(C.indices, ci) and np.array_equal(C.data, v)
     rec = (tmp_path / "r.csv").read_text().split("\n")[1].split(",")
-    assert rec[14] == "1" and float(rec[20]) > 0 and len(rec) == 22          # gpus, first-pass ms, gather ms
+    assert rec[14] == "1" and float(rec[20]) > 0 and len(rec) == 28          # gpus, first-pass ms, gather ms, chunked pass, split tuning
+    assert int(rec[22]) >= 2 and float(rec[23]) > 0 and "chunks per rank, gather overlapped" in out.stdout     # the chunked pass ran
+    # ... and the chunked pass itself through the C ABI: three chunks of the one rank, assembled CSR = the oracle's
+    crp, cci, cv, pass_ms, tail_ms = hostio.mgpu_chunked_pass([0], rows, cols, I, J, V, 3)
+    assert np.array_equal(crp, rp) and np.array_equal(cci, ci) and np.array_equal(cv, v) and pass_ms > 0
     # a device that does not exist is refused, not ignored
     out = subprocess.run([hostio.CLI_PATH, mtx, "0", "--gpus", "64"], env=env, capture_output=True, text=True, timeout=180)
     assert out.returncode == 2 and "visible" in out.stderr
