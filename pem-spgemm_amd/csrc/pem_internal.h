@@ -251,6 +251,10 @@ inline int bits_for(uint64_t count)   // bits needed to represent values in [0, 
 // If d_total64 != nullptr the 64-bit total is also stored there.
 pem_status exclusive_scan_i32(pem_ctx *ctx, const int *in, int *out, size_t n, int64_t *d_total64);
 
+// two independent arrays (any lengths): one launch where both are mid-size, else two
+pem_status exclusive_scan_i32_two(pem_ctx *ctx, const int *in_a, int *out_a, size_t na, int64_t *d_total_a, const int *in_b, int *out_b, size_t nb,
+                                  int64_t *d_total_b);
+
 // two arrays of equal length scanned in place by one set of launches
 pem_status exclusive_scan_i32_pair(pem_ctx *ctx, int *a, int *b, size_t n, int64_t *d_total_a, int64_t *d_total_b);
 

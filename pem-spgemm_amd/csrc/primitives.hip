@@ -464,13 +464,30 @@ __global__ void __launch_bounds__(1024) scan_small_kernel(const int *in, int *ou
 constexpr int SCAN_MID_ITEMS = 2048, SCAN_MID_BLOCKS = 128;
 constexpr unsigned long long SCAN_MID_VALID = 1ull << 63;
 
-__global__ void __launch_bounds__(256) scan_mid_kernel(const int *in, int *out, size_t n, unsigned long long *state, int *ctl /* done, ticket */,
-                                                       long long *__restrict__ total64, int *__restrict__ flags, int stall_ticket)
+// (blockIdx.y: up to two independent arrays scanned by one launch -- step 1 scans its per-row tile counts and its per-256-pairs
+// first-pair counts back to back; each array has its own look-back words, and blocks past an array's end leave at once)
+struct ScanMidArgs {
+    const int *in[2];
+    int *out[2];
+    size_t n[2];
+    long long *total64[2];
+    int nblk[2];
+};
+__global__ void __launch_bounds__(256) scan_mid_kernel(ScanMidArgs args, unsigned long long *state_all, int *__restrict__ flags, int stall_ticket)
 {
     __shared__ long long wsum[4];
     __shared__ long long s_excl;
     __shared__ int s_ticket;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nblk = gridDim.x;
+    const int y = blockIdx.y;
+    const int nblk = args.nblk[y];
+    if ((int)blockIdx.x >= nblk) return;
+    const int *in = args.in[y];
+    int *out = args.out[y];
+    const size_t n = args.n[y];
+    long long *total64 = args.total64[y];
+    unsigned long long *state = state_all + (size_t)y * (SCAN_MID_BLOCKS + 2);
+    int *ctl = reinterpret_cast<int *>(state + SCAN_MID_BLOCKS);   // done, ticket
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_ticket = atomicAdd(&ctl[1], 1);
     __syncthreads();
     const int blk = s_ticket;
@@ -546,6 +563,42 @@ __global__ void __launch_bounds__(256) scan_mid_kernel(const int *in, int *out, 
     }
 }
 
+static pem_status scan_mid_state(pem_ctx *ctx)
+{
+    if (!ctx->scan_state.p) {   // look-back words + completion counter (two sets: scan_mid_kernel takes two arrays), zero between scans
+        PEM_TRY(ctx->scan_state.reserve(sizeof(unsigned long long) * 2 * (SCAN_MID_BLOCKS + 2)));
+        PEM_HIP(hipMemsetAsync(ctx->scan_state.p, 0, sizeof(unsigned long long) * 2 * (SCAN_MID_BLOCKS + 2), ctx->stream));
+    }
+    return PEM_OK;
+}
+
+// two independent arrays, each in place or out of place: one launch where both are mid-size (8192 < n <= 262144), else two calls
+pem_status exclusive_scan_i32_two(pem_ctx *ctx, const int *in_a, int *out_a, size_t na, int64_t *d_total_a, const int *in_b, int *out_b, size_t nb,
+                                  int64_t *d_total_b)
+{
+    auto mid = [](size_t n) { return n > 8192 && n <= (size_t)SCAN_MID_ITEMS * SCAN_MID_BLOCKS; };
+    const bool aligned = !((reinterpret_cast<uintptr_t>(in_a) | reinterpret_cast<uintptr_t>(out_a) | reinterpret_cast<uintptr_t>(in_b) |
+                            reinterpret_cast<uintptr_t>(out_b)) & 15);
+    if (ctx->dbg_scan_force || !aligned || !mid(na) || !mid(nb)) {
+        PEM_TRY(exclusive_scan_i32(ctx, in_a, out_a, na, d_total_a));
+        return exclusive_scan_i32(ctx, in_b, out_b, nb, d_total_b);
+    }
+    PEM_TRY(scan_mid_state(ctx));
+    ScanMidArgs a = {};
+    a.in[0] = in_a;
+    a.out[0] = out_a;
+    a.n[0] = na;
+    a.total64[0] = reinterpret_cast<long long *>(d_total_a);
+    a.nblk[0] = (int)((na + SCAN_MID_ITEMS - 1) / SCAN_MID_ITEMS);
+    a.in[1] = in_b;
+    a.out[1] = out_b;
+    a.n[1] = nb;
+    a.total64[1] = reinterpret_cast<long long *>(d_total_b);
+    a.nblk[1] = (int)((nb + SCAN_MID_ITEMS - 1) / SCAN_MID_ITEMS);
+    PEM_LAUNCH(ctx, scan_mid_kernel, dim3((unsigned)std::max(a.nblk[0], a.nblk[1]), 2), 256, a, ctx->scan_state.as<unsigned long long>(), ctx->d_flags, -1);
+    return PEM_OK;
+}
+
 pem_status exclusive_scan_i32(pem_ctx *ctx, const int *in, int *out, size_t n, int64_t *d_total64)
 {
     if (n == 0) {
@@ -566,14 +619,14 @@ pem_status exclusive_scan_i32(pem_ctx *ctx, const int *in, int *out, size_t n, i
         return PEM_OK;
     }
     if (force ? force == 2 : n <= (size_t)SCAN_MID_ITEMS * SCAN_MID_BLOCKS) {
-        if (!ctx->scan_state.p) {   // look-back words + completion counter, zero between scans
-            PEM_TRY(ctx->scan_state.reserve(sizeof(unsigned long long) * (SCAN_MID_BLOCKS + 2)));
-            PEM_HIP(hipMemsetAsync(ctx->scan_state.p, 0, sizeof(unsigned long long) * (SCAN_MID_BLOCKS + 2), ctx->stream));
-        }
-        unsigned long long *state = ctx->scan_state.as<unsigned long long>();
-        PEM_LAUNCH(ctx, scan_mid_kernel, (unsigned)((n + SCAN_MID_ITEMS - 1) / SCAN_MID_ITEMS), 256, in, out, n, state,
-                   reinterpret_cast<int *>(state + SCAN_MID_BLOCKS), reinterpret_cast<long long *>(d_total64), ctx->d_flags,
-                   ctx->dbg_scan_stall_ticket);
+        PEM_TRY(scan_mid_state(ctx));
+        ScanMidArgs a = {};
+        a.in[0] = in;
+        a.out[0] = out;
+        a.n[0] = n;
+        a.total64[0] = reinterpret_cast<long long *>(d_total64);
+        a.nblk[0] = (int)((n + SCAN_MID_ITEMS - 1) / SCAN_MID_ITEMS);
+        PEM_LAUNCH(ctx, scan_mid_kernel, (unsigned)a.nblk[0], 256, a, ctx->scan_state.as<unsigned long long>(), ctx->d_flags, ctx->dbg_scan_stall_ticket);
         return PEM_OK;
     }
     int nblk = (int)((n + SCAN_BLOCK_ITEMS - 1) / SCAN_BLOCK_ITEMS);

@@ -922,7 +922,7 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
         // pair_col's sign bit; the marks per 256 pairs of the stream are counted for step 2's dense tile index.
         const int nseg = (nl + 63) >> 6;
         int mytiles = 0;
-#pragma unroll 2
+
         for (int g = wave; g < nseg; g += WAVES) {
             const int s = 64 * g + lane;
             const bool valid = s < nl;
@@ -1763,10 +1763,10 @@ static pem_status step1_rows_impl(pem_ctx *ctx, pem_cplan *p)
                        p->row_lbase.as<int>(), p->prod_a.as<int>(), p->prod_b.as<int>(),
                        p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->pair_col.as<int>(), p->blk_heads.as<int>(), p->c_tile_rowptr.as<int>());
         }
-        // first pairs per 256 pairs -> C tiles in front of every 256 pairs (step 2's dense tile index)
-        PEM_TRY(exclusive_scan_i32(ctx, p->blk_heads.as<int>(), p->blk_heads.as<int>(), nblk, nullptr));
-        // _C_rowPtr = exclusive scan of the per-row tile counts (spgemm.cu:1168); total = T_C
-        PEM_TRY(exclusive_scan_i32(ctx, p->c_tile_rowptr.as<int>(), p->c_tile_rowptr.as<int>(), (size_t)mt, ctx->d_scalars + 1));
+        // first pairs per 256 pairs -> C tiles in front of every 256 pairs (step 2's dense tile index); and
+        // _C_rowPtr = exclusive scan of the per-row tile counts (spgemm.cu:1168), total = T_C -- one launch where both are mid-size
+        PEM_TRY(exclusive_scan_i32_two(ctx, p->blk_heads.as<int>(), p->blk_heads.as<int>(), nblk, nullptr, p->c_tile_rowptr.as<int>(),
+                                       p->c_tile_rowptr.as<int>(), (size_t)mt, ctx->d_scalars + 1));
         if (p->warm_pass) {
             TC = p->w_TC;
         } else {
