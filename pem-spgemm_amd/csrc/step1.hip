@@ -190,7 +190,14 @@ __global__ void __launch_bounds__(256) s1_total_kernel(const int *__restrict__ a
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) len += __shfl_xor(len, d, 64);
-    if ((threadIdx.x & 63) == 0 && len) atomicAdd(total, (unsigned long long)len);
+    // one atomic per block (one per wave -- 10 k of them on the one word -- took 128 us of a first pass: 11 ns apiece)
+    __shared__ long long wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = len;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (s) atomicAdd(total, (unsigned long long)s);
+    }
 }
 
 #ifdef PEM_S1_DEBUG
