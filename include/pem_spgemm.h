@@ -221,7 +221,9 @@ pem_status pem_set_graph_replay(pem_ctx *ctx, int on);
 
 /* ---- a14: tiled C -> CSR / sorted COO (spgemm.cu:663-695, 1493-1543) ------------------- */
 /* rowptr has (row_end-row_begin)+1 entries and is relative to the slice (rowptr[0] = 0);
- * column indices ascend inside a row.  COO rows are absolute, sorted by (row, col). */
+ * column indices ascend inside a row.  COO rows are absolute, sorted by (row, col).
+ * The _device forms write device arrays and return without waiting for the stream; pem_ctx_synchronize() is where a
+ * failure inside their kernels (a device scan that gave up: PEM_E_HIP) is reported.  The host forms wait and report it. */
 pem_status pem_c_export_csr(pem_ctx *ctx, const pem_cplan *plan, int64_t *nnz, int32_t *rowptr,
                             int32_t *colidx, double *vals);
 pem_status pem_c_export_csr_device(pem_ctx *ctx, const pem_cplan *plan, int32_t *d_rowptr,

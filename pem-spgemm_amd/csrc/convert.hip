@@ -349,8 +349,11 @@ extern "C" pem_status pem_ctx_destroy(pem_ctx *ctx)
 extern "C" pem_status pem_ctx_synchronize(pem_ctx *ctx)
 {
     if (!ctx) return PEM_E_INVALID;
-    PEM_HIP(hipStreamSynchronize(ctx->stream));
-    return PEM_OK;
+    PEM_ENTER(ctx);
+    // also where an asynchronous call (pem_c_export_csr_device) reports that one of its device scans gave up
+    int hf[NUM_FLAGS];
+    PEM_TRY(read_flags(ctx, hf));   // (synchronises the stream)
+    return check_internal(hf);
 }
 
 extern "C" pem_status pem_ctx_reserve(pem_ctx *ctx, int64_t bytes)
@@ -524,6 +527,7 @@ static pem_status build_tiled(pem_ctx *ctx, pem_tiled *T, DevBuf &k0, DevBuf &k1
     PEM_TRY(read_scalars(ctx, ctx->d_scalars, 1, &ntiles));
     int hf[NUM_FLAGS];
     PEM_TRY(read_flags(ctx, hf));
+    PEM_TRY(check_internal(hf));   // (the scan gave up: ntiles and every offset behind it would be wrong)
     if (hf[FLAG_RANGE]) {
         set_error("index out of range for a %d x %d matrix", T->rows, T->cols);
         return PEM_E_INVALID;
@@ -949,6 +953,8 @@ extern "C" pem_status pem_tiled_load(pem_ctx *ctx, const char *path, const pem_c
         PEM_HIP(hipMemsetAsync(head.p, 0, sizeof(int) * (nnz + 1), st));
         if (nt) PEM_LAUNCH(ctx, cache_heads_kernel, grid_for(nt, 256), 256, T->tile_nnz_ptr.as<int>(), (long long)nt, head.as<int>());
         PEM_TRY(exclusive_scan_i32(ctx, head.as<int>(), head.as<int>(), nnz, nullptr));
+        PEM_TRY(read_flags(ctx, hf));
+        PEM_TRY(check_internal(hf));
         lap("check");
         return derive_tiled(ctx, T, head.as<int>(), bits_tr, bits_tc);
     };

@@ -373,7 +373,9 @@ static pem_status export_csr_impl(pem_ctx *ctx, const pem_cplan *p, int64_t *nnz
         PEM_HIP(hipMemcpyAsync(colidx, dC.p, sizeof(int) * nz, hipMemcpyDeviceToHost, ctx->stream));
         PEM_HIP(hipMemcpyAsync(vals, dV.p, sizeof(VT) * nz, hipMemcpyDeviceToHost, ctx->stream));
     }
-    PEM_HIP(hipStreamSynchronize(ctx->stream));
+    int hf[NUM_FLAGS];
+    PEM_TRY(read_flags(ctx, hf));    // (synchronises) -- the export's scans gave up: the row pointer just copied is not valid
+    PEM_TRY(check_internal(hf));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) ctx->timings.export_ms = ms;
     return PEM_OK;

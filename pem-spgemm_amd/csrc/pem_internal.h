@@ -265,6 +265,7 @@ pem_status radix_sort_u64_u32(pem_ctx *ctx, uint64_t *k0, uint64_t *k1, uint32_t
 
 pem_status zero_flags(pem_ctx *ctx);
 pem_status read_flags(pem_ctx *ctx, int *host_flags /*NUM_FLAGS*/);   // synchronises the stream
+pem_status check_internal(const int *host_flags);   // PEM_E_HIP if a device primitive gave up (FLAG_INTERNAL): the arrays behind it are not valid
 // copy `count` int64 scalars from device to the pinned page and synchronise
 pem_status read_scalars(pem_ctx *ctx, const int64_t *d_src, int count, int64_t *host_dst);
 

@@ -40,7 +40,6 @@ __device__ __forceinline__ double pem_fma(double a, double b, double c) { return
 __device__ __forceinline__ float pem_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 // host side (each in the unit of its step)
-pem_status check_internal(const int *hf);
 pem_status step_elapsed(pem_ctx *ctx, int e0, int e1, double *dst);
 void retire_graph(pem_ctx *ctx, pem_cplan *plan);
 pem_status step1_impl(pem_ctx *ctx, pem_cplan *p, bool allow_warm);

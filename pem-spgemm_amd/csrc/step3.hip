@@ -79,7 +79,7 @@ template <bool IDX32, typename T> __device__ __forceinline__ T s3_ld(const T *__
 // 64-word LDS strip, one ballot turns the strip into a bit mask, and an entry's tile is (tiles started before the trip) +
 // (marks at or below its lane) - 1.
 template <typename VT, bool DEEP, bool BAND = false, bool DECODE = false, bool IDX32 = false, bool MARK = false>
-__global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
+__global__ void __launch_bounds__(256, DEEP ? 1 : 8) s3_accumulate_wide_kernel(
     const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b, long long ntc,
     const int *__restrict__ c_tile_nnz_ptr, long long nnz_c, const uint8_t *__restrict__ c_rowcolidx, VT *__restrict__ c_vals,
     const int *__restrict__ a_nnz_ptr, const VT *__restrict__ a_vals, const uint32_t *__restrict__ a_rec,
@@ -153,6 +153,7 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
     for (int ebase = e_begin; ebase < e_end; ebase += 64) {   // wave-uniform trip count: every lane stays live for the shuffles
         const int e = ebase + lane;
         const bool valid = e < e_end;
+        const int nvalid = e_end - ebase < 64 ? e_end - ebase : 64;   // (wave-uniform)
         // tile of entry e: largest lane index ti with off[ti] <= e (offsets are non-decreasing)
         int ti = 0;
         if constexpr (MARK) {
@@ -177,13 +178,18 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
                 if (probe <= e) ti += step;
             }
         }
-        const int p0 = __shfl(my_p0, ti, 64), p1 = __shfl(my_p1, ti, 64);
+        // The shallow kernel keeps every lane to the end of the trip (its third and later pairs are fetched by the wave together, below):
+        // a lane past the last entry takes no pairs and stores nothing.
+        const int p0 = __shfl(my_p0, ti, 64), p1_ = __shfl(my_p1, ti, 64);
+        const int p1 = (DEEP || valid) ? p1_ : p0;
         const int a0 = __shfl(my_a0, ti, 64), b0 = __shfl(my_b0, ti, 64), av0 = __shfl(my_av0, ti, 64), bv0 = __shfl(my_bv0, ti, 64);
         // (every shuffle sits in front of the `continue`: a lane that has left cannot be read from)
         const int a1 = __shfl(my_a1, ti, 64), b1 = __shfl(my_b1, ti, 64), av1 = __shfl(my_av1, ti, 64), bv1 = __shfl(my_bv1, ti, 64);
         const int toff = DECODE ? __shfl(my_off, ti, 64) : 0;
-        if (!valid) continue;
-        if (BAND && p1 - p0 >= S3_BAND_MIN) continue;   // many-pair tiles: s3_band_kernel's
+        if constexpr (DEEP) {
+            if (!valid) continue;
+            if (BAND && p1 - p0 >= S3_BAND_MIN) continue;   // many-pair tiles: s3_band_kernel's
+        }
         int r, c;
         if constexpr (DECODE) {
             const unsigned n = (unsigned)(e - toff);                     // entry n of its tile, row-major
@@ -215,38 +221,100 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
             const bool g1 = k >= (m & 1u);
             c = (g8 ? 8 : 0) + (g4 ? 4 : 0) + (g2 ? 2 : 0) + (g1 ? 1 : 0);
         } else {
-            const unsigned rc = c_rowcolidx[e];
+            const unsigned rc = valid ? c_rowcolidx[e] : 0u;
             r = rc >> 4;
             c = rc & 15;
         }
         VT acc = VT(0);
         int p = p0;
         if (!DEEP) {   // first pair: everything but the two records and the values is already here
-            const unsigned aw = s3_ld<IDX32>(a_rec, 16ll * a0 + r), bw = s3_ld<IDX32>(b_rec_t, 16ll * b0 + c);
-            const unsigned am = aw & 0xFFFFu, bm = bw & 0xFFFFu;
-            unsigned m = am & bm;
-            const int ao = av0 + (int)(aw >> 16), bo = bv0 + (int)(bw >> 16);
-            while (m) {
-                const int kk = __builtin_ctz(m);
-                m &= m - 1;
-                const unsigned below = (1u << kk) - 1u;
-                acc = pem_fma(s3_ld<IDX32>(a_vals, (long long)ao + __popc(am & below)), s3_ld<IDX32>(b_vals_t, (long long)bo + __popc(bm & below)), acc);
+            // The step is bound by the LATENCY of its dependent gathers (records -> values), eight waves per SIMD being all the
+            // hardware holds: halving the resident waves took it from 0.51 to 0.93 ms.  So the second pair's
+            // records go out beside the first pair's, and the first product of either pair is gathered before anything is summed:
+            // two round trips for an entry with two pairs instead of four.  The sums still run pair by pair, bit by bit.
+            const bool has1 = p0 < p1, has2 = p0 + 1 < p1;
+            // the third and later pairs of the trip's tiles (64 % of webbase-1M's entries lie in tiles with three to eight pairs): the
+            // pairs of consecutive tiles are consecutive, so the wave fetches the trip's whole pair range ONCE, one pair per lane --
+            // ids, then value offsets -- and a lane reads the record of ITS q-th pair by shuffle.  Before: every lane gathered ids,
+            // offsets and records per pair (six wave-wide vector-memory instructions and four dependent round trips per pair; the
+            // step is bound by the texture addresser, 16 cycles per such instruction -- DESIGN.md section 4); now two per pair.
+            const int P0 = __builtin_amdgcn_readfirstlane(p0);
+            const int Pn = __builtin_amdgcn_readlane(p1, nvalid - 1) - P0;       // (the trip's lanes are a prefix: nvalid of them)
+            const bool staged = __ballot(p1 - p0 > 2) != 0ull && Pn <= 64;
+            int sa = 0, sb = 0, sav = 0, sbv = 0;
+            if (staged && lane < Pn) {
+                sa = s3_ld<IDX32>(pairs_a, (long long)P0 + lane);
+                sb = s3_ld<IDX32>(pairs_b, (long long)P0 + lane);
             }
-            ++p;
-            {
-                if (p < p1) {             // second pair
-                    const unsigned aw1 = s3_ld<IDX32>(a_rec, 16ll * a1 + r), bw1 = s3_ld<IDX32>(b_rec_t, 16ll * b1 + c);
-                    const unsigned am1 = aw1 & 0xFFFFu, bm1 = bw1 & 0xFFFFu;
-                    unsigned m1 = am1 & bm1;
-                    const int ao1 = av1 + (int)(aw1 >> 16), bo1 = bv1 + (int)(bw1 >> 16);
-                    while (m1) {
-                        const int kk = __builtin_ctz(m1);
-                        m1 &= m1 - 1;
-                        const unsigned below = (1u << kk) - 1u;
-                        acc = pem_fma(s3_ld<IDX32>(a_vals, (long long)ao1 + __popc(am1 & below)), s3_ld<IDX32>(b_vals_t, (long long)bo1 + __popc(bm1 & below)), acc);
-                    }
-                    ++p;
+            unsigned aw = 0, bw = 0;
+            if (has1) {
+                aw = s3_ld<IDX32>(a_rec, 16ll * a0 + r);
+                bw = s3_ld<IDX32>(b_rec_t, 16ll * b0 + c);
+            }
+            unsigned aw1 = 0, bw1 = 0;
+            if (has2) {
+                aw1 = s3_ld<IDX32>(a_rec, 16ll * a1 + r);
+                bw1 = s3_ld<IDX32>(b_rec_t, 16ll * b1 + c);
+            }
+            if (staged && lane < Pn) {
+                sav = s3_ld<IDX32>(a_nnz_ptr, sa);
+                sbv = s3_ld<IDX32>(b_nnz_ptr, sb);
+            }
+            const unsigned am = aw & 0xFFFFu, bm = bw & 0xFFFFu, am1 = aw1 & 0xFFFFu, bm1 = bw1 & 0xFFFFu;
+            unsigned m = am & bm, m1 = am1 & bm1;
+            const int ao = av0 + (int)(aw >> 16), bo = bv0 + (int)(bw >> 16), ao1 = av1 + (int)(aw1 >> 16), bo1 = bv1 + (int)(bw1 >> 16);
+            VT x0 = VT(0), y0 = VT(0), x1 = VT(0), y1 = VT(0);
+            if (m) {
+                const unsigned below = (1u << __builtin_ctz(m)) - 1u;
+                x0 = s3_ld<IDX32>(a_vals, (long long)ao + __popc(am & below));
+                y0 = s3_ld<IDX32>(b_vals_t, (long long)bo + __popc(bm & below));
+            }
+            if (m1) {
+                const unsigned below = (1u << __builtin_ctz(m1)) - 1u;
+                x1 = s3_ld<IDX32>(a_vals, (long long)ao1 + __popc(am1 & below));
+                y1 = s3_ld<IDX32>(b_vals_t, (long long)bo1 + __popc(bm1 & below));
+            }
+            if (m) {
+                acc = pem_fma(x0, y0, acc);
+                m &= m - 1;
+                while (m) {
+                    const int kk = __builtin_ctz(m);
+                    m &= m - 1;
+                    const unsigned below = (1u << kk) - 1u;
+                    acc = pem_fma(s3_ld<IDX32>(a_vals, (long long)ao + __popc(am & below)), s3_ld<IDX32>(b_vals_t, (long long)bo + __popc(bm & below)), acc);
                 }
+            }
+            if (m1) {
+                acc = pem_fma(x1, y1, acc);
+                m1 &= m1 - 1;
+                while (m1) {
+                    const int kk = __builtin_ctz(m1);
+                    m1 &= m1 - 1;
+                    const unsigned below = (1u << kk) - 1u;
+                    acc = pem_fma(s3_ld<IDX32>(a_vals, (long long)ao1 + __popc(am1 & below)), s3_ld<IDX32>(b_vals_t, (long long)bo1 + __popc(bm1 & below)), acc);
+                }
+            }
+            p += has2 ? 2 : has1 ? 1 : 0;
+            if (staged) {
+                for (int q = 2;; ++q) {
+                    const bool on = p0 + q < p1;
+                    if (__ballot(on) == 0ull) break;                            // wave-uniform
+                    const int src = on ? p0 + q - P0 : 0;
+                    const int a = __shfl(sa, src, 64), b = __shfl(sb, src, 64), av = __shfl(sav, src, 64), bv = __shfl(sbv, src, 64);
+                    if (on) {
+                        const unsigned awq = s3_ld<IDX32>(a_rec, 16ll * a + r), bwq = s3_ld<IDX32>(b_rec_t, 16ll * b + c);
+                        const unsigned amq = awq & 0xFFFFu, bmq = bwq & 0xFFFFu;
+                        unsigned mq = amq & bmq;
+                        const int aoq = av + (int)(awq >> 16), boq = bv + (int)(bwq >> 16);
+                        while (mq) {
+                            const int kk = __builtin_ctz(mq);
+                            mq &= mq - 1;
+                            const unsigned below = (1u << kk) - 1u;
+                            acc = pem_fma(s3_ld<IDX32>(a_vals, (long long)aoq + __popc(amq & below)), s3_ld<IDX32>(b_vals_t, (long long)boq + __popc(bmq & below)), acc);
+                        }
+                    }
+                }
+                p = p1;
             }
         }
         // DEEP: plans averaging two or more pairs per C tile (3.1 on cage15-class inputs, 30+ where a band multiplies itself).
@@ -332,10 +400,13 @@ __global__ void __launch_bounds__(256) s3_accumulate_wide_kernel(
                 acc = pem_fma(s3_ld<IDX32>(a_vals, (long long)ao + __popc(am & below)), s3_ld<IDX32>(b_vals_t, (long long)bo + __popc(bm & below)), acc);
             }
         }
+        // (streamed past the L2 -- nontemporal: C's values are never read here, and the records and values the gathers come back
+        // to stay resident: 0.51 -> 0.47 ms on the webbase-1M stand-in)
+        if (!valid) continue;
         if constexpr (IDX32)
-            *reinterpret_cast<VT *>(reinterpret_cast<char *>(c_vals) + (size_t)((unsigned)e * (unsigned)sizeof(VT))) = acc;
+            __builtin_nontemporal_store(acc, reinterpret_cast<VT *>(reinterpret_cast<char *>(c_vals) + (size_t)((unsigned)e * (unsigned)sizeof(VT))));
         else
-            c_vals[e] = acc;
+            __builtin_nontemporal_store(acc, c_vals + e);
     }
         if (chunk_end >= e_hi) break;
     }

@@ -85,6 +85,33 @@ def test_error_paths(pkg, ctx):
     assert p.info()["nnz_c"] == 1
 
 
+def test_set_option_sends_the_stepwise_api_back_to_the_last_untouched_step(pkg, oracle, ctx):
+    """pem_cplan_set_option (include/pem_spgemm.h): a step that ran under the old value does not feed a step that runs under the
+    new one -- the step-wise calls fail with PEM_E_STATE until the plan has been taken through the steps the option touches."""
+    import matgen
+    rows, cols, I, J, V, _ = matgen.cases()["powerlaw_600"]
+    A = pkg.Tiled.from_coo(ctx, rows, cols, I, J, V)
+    want = oracle.Plan(oracle.Tiled(rows, cols, I, J, V), oracle.Tiled(rows, cols, I, J, V)).export_csr()
+    p = pkg.CPlan(ctx, A, A)
+    p.spgemm()
+    for opt, value, first_ok in (("s3_mark", 0, 3), ("s3_decode", 0, 2), ("prune", 0, 1)):
+        p.set_option(opt, value)
+        with pytest.raises(pkg.PemError) as e:
+            p.export_csr()                                   # step 3 has not run under the new value
+        assert e.value.status == -6, opt                     # PEM_E_STATE
+        steps = (p.step1, p.step2, p.step3)
+        for k in (3, 2):                                     # a later step than the first one allowed: refused, nothing run
+            if k > first_ok:
+                with pytest.raises(pkg.PemError) as e:
+                    steps[k - 1]()
+                assert e.value.status == -6, (opt, k)
+        for k in range(first_ok, 4):
+            steps[k - 1]()
+        got = p.export_csr()
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w), opt
+
+
 def test_cli_end_to_end(pkg, oracle, standins, tmp_path):
     hostio = importlib.import_module("pem_spgemm_amd.hostio")
     rows, cols, I, J, V = standins.make("scircuit", scale=0.01)
