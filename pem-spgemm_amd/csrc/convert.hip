@@ -108,14 +108,24 @@ __global__ void __launch_bounds__(256) conv_tile_meta_kernel(const uint8_t *__re
     const int r = threadIdx.x & 15;
     const int grp = (threadIdx.x & 63) >> 4;
     const bool live = t < ntiles;
-    unsigned mask = 0;
+    // The sixteen lanes of a tile read its (row, col) bytes TOGETHER, sixteen per trip, and OR each entry's column bit into its
+    // row's word in LDS (word = lane of the row; only this wave touches it).  Every lane walking all of the tile's bytes on its own
+    // was a chain of dependent loads per tile, and five vector-ALU instructions per (lane, entry).
+    __shared__ unsigned s_rowmask[256];
+    s_rowmask[threadIdx.x] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (live) {
-        int e0 = tile_nnz_ptr[t], e1 = tile_nnz_ptr[t + 1];
-        for (int e = e0; e < e1; ++e) {
-            unsigned rc = rowcolidx[e];
-            if ((int)(rc >> 4) == r) mask |= 1u << (rc & 15);
+        const int e0 = tile_nnz_ptr[t], e1 = tile_nnz_ptr[t + 1];
+        for (int e = e0 + r; e < e1; e += 16) {
+            const unsigned rc = rowcolidx[e];
+            atomicOr(&s_rowmask[(threadIdx.x & ~15u) + (rc >> 4)], 1u << (rc & 15u));
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const unsigned mask = s_rowmask[threadIdx.x];
     // exclusive scan of the row populations across the 16-lane group
     int cnt = __popc(mask), inc = cnt;
 #pragma unroll
@@ -123,12 +133,20 @@ __global__ void __launch_bounds__(256) conv_tile_meta_kernel(const uint8_t *__re
         int v = __shfl_up(inc, d, 16);
         if (r >= d) inc += v;
     }
-    unsigned bt = 0;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        unsigned long long ball = __ballot((mask >> m) & 1u);
-        unsigned mine = (unsigned)(ball >> (16 * grp)) & 0xFFFFu;
-        if (r == m) bt = mine;
+    // transposed masks: the 16 x 16 bit matrix held one row per lane is transposed by four butterfly stages (swap the off-diagonal
+    // s x s blocks with lane r ^ s, s = 8, 4, 2, 1; ds_swizzle: no LDS memory, no address arithmetic) -- ~25 vector-ALU
+    // instructions where sixteen ballots with per-lane extraction took ~190 of the kernel's 305 (it was ALU-bound: 96 us)
+    unsigned bt = mask;
+    {
+        unsigned y;
+        y = (unsigned)__builtin_amdgcn_ds_swizzle((int)bt, (8 << 10) | 0x1F);
+        bt = (r & 8) ? ((bt & 0xFF00u) | ((y >> 8) & 0x00FFu)) : ((bt & 0x00FFu) | ((y & 0x00FFu) << 8));
+        y = (unsigned)__builtin_amdgcn_ds_swizzle((int)bt, (4 << 10) | 0x1F);
+        bt = (r & 4) ? ((bt & 0xF0F0u) | ((y >> 4) & 0x0F0Fu)) : ((bt & 0x0F0Fu) | ((y & 0x0F0Fu) << 4));
+        y = (unsigned)__builtin_amdgcn_ds_swizzle((int)bt, (2 << 10) | 0x1F);
+        bt = (r & 2) ? ((bt & 0xCCCCu) | ((y >> 2) & 0x3333u)) : ((bt & 0x3333u) | ((y & 0x3333u) << 2));
+        y = (unsigned)__builtin_amdgcn_ds_swizzle((int)bt, (1 << 10) | 0x1F);
+        bt = (r & 1) ? ((bt & 0xAAAAu) | ((y >> 1) & 0x5555u)) : ((bt & 0x5555u) | ((y & 0x5555u) << 1));
     }
     // occupancy word: which columns hold an entry (OR of the row masks) | which rows are non-empty << 16
     unsigned co = mask;
@@ -495,8 +513,10 @@ static pem_status derive_tiled(pem_ctx *ctx, pem_tiled *T, const int *headx, int
                    k0.as<uint64_t>(), v0.as<uint32_t>());
         uint64_t *ck = nullptr;
         uint32_t *cp = nullptr;
+        // (the tiles arrive sorted by (tile row, tile column) and the passes are stable: sorting on the tile-column digits alone
+        // leaves the tile rows ascending inside every column -- two passes where the whole key took four)
         PEM_TRY(radix_sort_u64_u32(ctx, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint32_t>(), v1.as<uint32_t>(), nt, bits_tr + bits_tc,
-                                   &ck, &cp));
+                                   &ck, &cp, bits_tr));
         PEM_LAUNCH(ctx, conv_tile_csc_kernel, grid_for(nt, 256), 256, ck, cp, (long long)ntiles, bits_tr, T->tile_cols,
                    T->tile_colptr.as<int>(), T->tile_rowidx.as<int>(), T->tile_offsets.as<int>());
     }

@@ -258,10 +258,10 @@ pem_status exclusive_scan_i32_two(pem_ctx *ctx, const int *in_a, int *out_a, siz
 // two arrays of equal length scanned in place by one set of launches
 pem_status exclusive_scan_i32_pair(pem_ctx *ctx, int *a, int *b, size_t n, int64_t *d_total_a, int64_t *d_total_b);
 
-// Stable LSD radix sort of (key, payload) on key bits [0, nbits).  Buffers ping-pong; on
+// Stable LSD radix sort of (key, payload) on key bits [first_bit, nbits).  Buffers ping-pong; on
 // return *keys_out / *vals_out point at the buffers holding the sorted data.
 pem_status radix_sort_u64_u32(pem_ctx *ctx, uint64_t *k0, uint64_t *k1, uint32_t *v0, uint32_t *v1,
-                              size_t n, int nbits, uint64_t **keys_out, uint32_t **vals_out);
+                              size_t n, int nbits, uint64_t **keys_out, uint32_t **vals_out, int first_bit = 0);
 
 pem_status zero_flags(pem_ctx *ctx);
 pem_status read_flags(pem_ctx *ctx, int *host_flags /*NUM_FLAGS*/);   // synchronises the stream

@@ -775,7 +775,10 @@ pem_status exclusive_scan_i32_pair(pem_ctx *ctx, int *a, int *b, size_t n, int64
 // ------------------------------------------------------------------------------------------
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
-constexpr int RS_ROUNDS = 16;
+#ifndef PEM_RS_ROUNDS
+#define PEM_RS_ROUNDS 16
+#endif
+constexpr int RS_ROUNDS = PEM_RS_ROUNDS;
 constexpr int RS_WAVE_ITEMS = RS_ROUNDS * 64;
 constexpr int RS_BLOCK_ITEMS = RS_WAVE_ITEMS * RS_WAVES;
 
@@ -785,9 +788,18 @@ __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint64_t *__r
     __shared__ int h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    size_t base = (size_t)blockIdx.x * RS_BLOCK_ITEMS;
-    size_t end = base + RS_BLOCK_ITEMS < n ? base + RS_BLOCK_ITEMS : n;
-    for (size_t i = base + threadIdx.x; i < end; i += RS_THREADS) atomicAdd(&h[(keys[i] >> shift) & 255], 1);
+    const size_t base = (size_t)blockIdx.x * RS_BLOCK_ITEMS + threadIdx.x;
+    // (all of the thread's keys in flight together, then the counting: a load per trip of a run-time loop was a chain of
+    // RS_BLOCK_ITEMS / RS_THREADS memory round trips)
+    uint64_t k[RS_BLOCK_ITEMS / RS_THREADS];
+#pragma unroll
+    for (int j = 0; j < RS_BLOCK_ITEMS / RS_THREADS; ++j) {
+        const size_t i = base + (size_t)j * RS_THREADS;
+        k[j] = i < n ? keys[i] : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < RS_BLOCK_ITEMS / RS_THREADS; ++j)
+        if (base + (size_t)j * RS_THREADS < n) atomicAdd(&h[(k[j] >> shift) & 255], 1);
     __syncthreads();
     hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
 }
@@ -804,60 +816,112 @@ __device__ __forceinline__ unsigned long long match_digit(unsigned d, unsigned l
     return peers;
 }
 
+// The scatter goes through LDS: ranks inside the block first (ballot match per round, per-wave digit counters), the items are
+// laid out digit by digit in a block-sized LDS image, and the image is then written out IN ORDER -- consecutive lanes hold
+// consecutive items of a digit's run (16 items on average), so a wave's store touches a handful of lines.  Writing every item
+// straight to its global position (rounds 1-3) made ~50 partial-line requests per store instruction and ran at the L2's request
+// rate, not at any bandwidth: 47 us per pass for 75 MB.
 __global__ void __launch_bounds__(RS_THREADS) rs_scatter_kernel(const uint64_t *__restrict__ kin, uint64_t *__restrict__ kout,
                                                                 const uint32_t *__restrict__ vin, uint32_t *__restrict__ vout,
                                                                 size_t n, int shift, const int *__restrict__ goff, int nblk)
 {
     __shared__ int wcnt[RS_WAVES][256];
+    __shared__ int lstart[256];                 // where digit d's run starts in the block image
+    __shared__ int gdelta[256];                 // global position of the run's first item minus lstart
+    __shared__ int wsum[RS_WAVES];
+    __shared__ uint64_t skey[RS_BLOCK_ITEMS];
+    __shared__ uint32_t sval[RS_BLOCK_ITEMS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int w = 0; w < RS_WAVES; ++w) wcnt[w][threadIdx.x] = 0;
     __syncthreads();
-    const size_t wbase = (size_t)blockIdx.x * RS_BLOCK_ITEMS + (size_t)wave * RS_WAVE_ITEMS;
+    const size_t bbase = (size_t)blockIdx.x * RS_BLOCK_ITEMS;
+    const size_t wbase = bbase + (size_t)wave * RS_WAVE_ITEMS;
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint64_t k[RS_ROUNDS];
+    uint32_t v[RS_ROUNDS];
+    unsigned info[RS_ROUNDS];
+    // every load of the wave first, all in flight together: with three waves per SIMD (a block is 4 096 items) a load per round,
+    // waited for in the round, was a chain of 2 x 16 memory round trips -- 30 of the kernel's 47 us
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const size_t idx = wbase + (size_t)r * 64 + lane;
+        k[r] = idx < n ? kin[idx] : ~0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const size_t idx = wbase + (size_t)r * 64 + lane;
+        v[r] = idx < n ? vin[idx] : 0u;
+    }
     // phase 1: per-wave digit counts
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; ++r) {
         size_t idx = wbase + (size_t)r * 64 + lane;
         bool valid = idx < n;
-        k[r] = valid ? kin[idx] : ~0ull;
         unsigned d = (unsigned)(k[r] >> shift) & 255u;
         unsigned long long vm = __ballot(valid);
         unsigned long long peers = match_digit(d, vm);
-        if (valid && (peers & lt) == 0) wcnt[wave][d] += __popcll(peers);   // lowest lane of each digit group
+        const int below = __popcll(peers & lt), all = __popcll(peers);
+        info[r] = (unsigned)below | ((unsigned)all << 8);                   // rank among the round's equal digits | their number
+        if (valid && below == 0) wcnt[wave][d] += all;                      // lowest lane of each digit group
     }
     __syncthreads();
-    // phase 2: thread d turns the 4 wave counts of digit d into running global positions
+    // phase 2: thread d: the block's count of digit d -> exclusive scan over the digits (run starts in the image); the wave
+    // counters become running positions in the image
     {
-        int run = goff[(size_t)threadIdx.x * nblk + blockIdx.x];
+        int c[RS_WAVES], tot = 0;
 #pragma unroll
         for (int w = 0; w < RS_WAVES; ++w) {
-            int c = wcnt[w][threadIdx.x];
+            c[w] = wcnt[w][threadIdx.x];
+            tot += c[w];
+        }
+        int inc = tot;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            int v = __shfl_up(inc, dlt, 64);
+            if (lane >= dlt) inc += v;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        int run = before + inc - tot;
+        lstart[threadIdx.x] = run;
+        gdelta[threadIdx.x] = goff[(size_t)threadIdx.x * nblk + blockIdx.x] - run;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) {
             wcnt[w][threadIdx.x] = run;
-            run += c;
+            run += c[w];
         }
     }
     __syncthreads();
-    // phase 3: rank inside the round by ballot, scatter
+    // phase 3: into the image (the ranks inside a round were noted in phase 1)
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; ++r) {
         size_t idx = wbase + (size_t)r * 64 + lane;
         bool valid = idx < n;
         unsigned d = (unsigned)(k[r] >> shift) & 255u;
-        unsigned long long vm = __ballot(valid);
-        unsigned long long peers = match_digit(d, vm);
+        const int below = (int)(info[r] & 255u), all = (int)(info[r] >> 8);
         int start = valid ? wcnt[wave][d] : 0;
-        int pos = start + __popcll(peers & lt);
-        if (valid && (peers & lt) == 0) wcnt[wave][d] = start + __popcll(peers);
+        int pos = start + below;
+        if (valid && below == 0) wcnt[wave][d] = start + all;
         if (valid) {
-            kout[pos] = k[r];
-            vout[pos] = vin[idx];
+            skey[pos] = k[r];
+            sval[pos] = v[r];
         }
+    }
+    __syncthreads();
+    // phase 4: the image, in order
+    const int nvalid = (int)(bbase + RS_BLOCK_ITEMS <= n ? (size_t)RS_BLOCK_ITEMS : n - bbase);
+    for (int i = threadIdx.x; i < nvalid; i += RS_THREADS) {
+        const uint64_t key = skey[i];
+        const int g = i + gdelta[(unsigned)(key >> shift) & 255u];
+        kout[g] = key;
+        vout[g] = sval[i];
     }
 }
 
 pem_status radix_sort_u64_u32(pem_ctx *ctx, uint64_t *k0, uint64_t *k1, uint32_t *v0, uint32_t *v1, size_t n, int nbits,
-                              uint64_t **keys_out, uint32_t **vals_out)
+                              uint64_t **keys_out, uint32_t **vals_out, int first_bit)
 {
     *keys_out = k0;
     *vals_out = v0;
@@ -872,7 +936,7 @@ pem_status radix_sort_u64_u32(pem_ctx *ctx, uint64_t *k0, uint64_t *k1, uint32_t
     int *hist = ctx->sort_hist.as<int>();
     uint64_t *kin = k0, *kout = k1;
     uint32_t *vin = v0, *vout = v1;
-    for (int shift = 0; shift < nbits; shift += 8) {
+    for (int shift = first_bit; shift < nbits; shift += 8) {
         PEM_LAUNCH(ctx, rs_hist_kernel, nblk, RS_THREADS, kin, n, shift, hist, nblk);
         PEM_TRY(exclusive_scan_i32(ctx, hist, hist, hcount, nullptr));
         PEM_LAUNCH(ctx, rs_scatter_kernel, nblk, RS_THREADS, kin, kout, vin, vout, n, shift, hist, nblk);

@@ -7,10 +7,11 @@
 // products by j yields the C tile list and the pair lists, in ascending k, in one pass.
 //
 // Round 4 layout of the default path (three phases, the row sorts concurrent):
-//   s1_expand_kernel     one wave per 64 consecutive A tiles of the slice: every product is formed and tested ONCE (the A
-//                        tile's occupied columns against the B tile's occupied rows); the live ones are written, in product
-//                        order, to the wave's own stretch of a scratch list (tile column | A tile, B tile) -- so a tile row's
-//                        live products are one or two contiguous pieces (one per 64-tile chunk the row touches)
+//   s1_expand_kernel     one 8-wave workgroup per 512 consecutive A tiles of the slice: every product is formed and tested
+//                        ONCE (the A tile's occupied columns against the B tile's occupied rows); the live ones are written,
+//                        in product order, to a stretch of the live list the workgroup takes from a bump counter (tile column |
+//                        A tile, B tile) -- so a tile row's live products are a few contiguous pieces (one per A tile; one per
+//                        chunk of 512 the row touches where the pieces lie end to end)
 //   s1_rowclass_kernel   per tile row: live total from the pieces, size class
 //   (scan of the totals: where the row's pairs go)
 //   s1_tiny_kernel / s1_rowsort_kernel<...>   per row: load the live keys (coalesced), sort by tile column, stream out the
@@ -618,10 +619,9 @@ __device__ __forceinline__ void s1_bitonic_regs(KeyT (&v)[EPT], KeyT *lds, const
 // phase 3: the row sorts.  A row's live products arrive as (tile column, position in the row's live list) keys; equal tile
 // columns stay in list (= product = ascending k) order because the position is part of the key, or -- the sixteen-wave bins --
 // because the keys sit in list order and the radix sort on the column bits is stable.  The sorted stream is written once:
-// pairs_a / pairs_b (final), and per distinct tile column (= C tile) its column + first pair into the row's SLOTS
-// (scratch_col / scratch_off; a row has at most as many C tiles as live products; the slots behind the last tile are marked and
-// carry the end of the row's pairs), the row's tile count, and for every 256-slot boundary inside the row's range the pair
-// (row, position) -- block_info, which is what lets step 2 index C tiles densely without scanning the slots.
+// pairs_a / pairs_b (final) and, per pair, pair_col = tile column | head << 31 (head: the first pair of a C tile); the row's
+// tile count; and the number of heads in every block of 256 pairs (blk_heads, scanned afterwards), which is what lets step 2
+// index C tiles densely without compacting anything.
 // ------------------------------------------------------------------------------------------
 // first pairs (C tiles) per 256 pairs of the stream, for step 2's dense tile index: 64 consecutive pairs starting at pair p0,
 // `bal` = which of them are first pairs; they lie in at most two blocks of 256
