@@ -211,12 +211,11 @@ __global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ p
         *reinterpret_cast<uint4 *>(c_mask + 8 * t + 4) = make_uint4((cw[4] << 16) | (cw[4] >> 16), (cw[5] << 16) | (cw[5] >> 16),
                                                                     (cw[6] << 16) | (cw[6] >> 16), (cw[7] << 16) | (cw[7] >> 16));
     };
-    for (long long pb = p_lo; pb < npairs; pb += 64) {
-        const bool over = pb >= p_lo + 256;                              // past the wave's own pairs: only the open tile is still ours
-        if (over && !open) break;
+    // one trip: 64 consecutive pairs from pb; col / ida / idb = the lane's pair_col word and pair ids; over = past the wave's own
+    // 256 pairs, where only the open tile is still ours
+    auto trip = [&](const long long pb, const int col, const int ida, const int idb, const bool over) {
         const long long p = pb + lane;
         const bool valid = p < npairs;
-        const int col = valid ? pair_col[p] : (int)0x80000000;           // (past the end of the pairs: a first pair, which closes the open tile)
         const bool head = col < 0;
         const unsigned long long H = __ballot(head);
         const int f = H ? __builtin_ctzll(H) : 64;                       // the trip's first first-pair
@@ -225,7 +224,7 @@ __global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ p
         const bool mine = valid && (lane < f ? open : !over);
         unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // natural layout: cw[q] = row 2q | row 2q+1 << 16
         if (mine) {
-            const S2Masks m = s2_load_masks(a_masks, b_masks, pairs_a[p], pairs_b[p]);
+            const S2Masks m = s2_load_masks(a_masks, b_masks, ida, idb);
             s2_pair_mask(m, bl, tid, cw);
         }
         // OR toward the first pair of every tile: lane i absorbs lane i + 1 while lane i + 1 is a further pair of the same tile
@@ -266,7 +265,7 @@ __global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ p
                 for (int q = 0; q < 8; ++q) ccw[q] = 0;
             }
         }
-        if (over) continue;
+        if (over) return;
         // tiles that start in this trip: all but the last are complete (the next first pair follows them inside the trip); the
         // last one stays open -- whether a further pair of it follows is only known in the next trip
         const unsigned long long Hv = H & __ballot(valid);
@@ -282,6 +281,26 @@ __global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ p
             open = true;
             t_next += __popcll(Hv);
         }
+    };
+    // The wave's own four trips: their pair words and ids are loaded up front, all in flight together -- a trip then waits for ONE
+    // round trip (its mask gathers) instead of three in a row (pair word -> ids -> masks): the kernel is a chain of dependent
+    // round trips per wave, not bandwidth (67 us for 0.25 GB).
+    int pc[4], pia[4], pib[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long long p = p_lo + 64 * j + lane;
+        const bool valid = p < npairs;
+        pc[j] = valid ? pair_col[p] : (int)0x80000000;                   // (past the end of the pairs: a first pair, which closes the open tile)
+        pia[j] = valid ? pairs_a[p] : 0;
+        pib[j] = valid ? pairs_b[p] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (p_lo + 64 * j < npairs) trip(p_lo + 64 * j, pc[j], pia[j], pib[j], false);
+    for (long long pb = p_lo + 256; pb < npairs && open; pb += 64) {     // the open tile runs on past the wave's pairs
+        const long long p = pb + lane;
+        const bool valid = p < npairs;
+        trip(pb, valid ? pair_col[p] : (int)0x80000000, valid ? pairs_a[p] : 0, valid ? pairs_b[p] : 0, true);
     }
     if (open && lane == 0) store_tile(c_t, c_j, c_p0, ccw);
     // entry counts per group of S2_GROUP tiles
