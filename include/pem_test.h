@@ -37,6 +37,11 @@ extern "C" {
 pem_status pem_debug_scan_i32(pem_ctx *ctx, const int32_t *in, int64_t n, int regime, int in_place, int stall_ticket,
                               int32_t *out, int64_t *total);
 
+/* Launches a kernel with a block size the runtime must refuse (2048 threads) on the context's stream and returns PEM_OK, as
+ * every asynchronous launch does: the refusal is kept in the context and comes back as PEM_E_HIP -- with the kernel's name in
+ * pem_last_error() -- from the next call that synchronises (pem_ctx_synchronize, the end of a pass, a conversion). */
+pem_status pem_debug_refused_launch(pem_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

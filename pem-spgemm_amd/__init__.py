@@ -38,6 +38,7 @@ ABI_SYMBOLS = [
     "pem_tiled_from_coo_f32", "pem_tiled_from_coo_device_f32", "pem_tiled_from_csr_f32", "pem_c_export_csr_f32",
     "pem_c_export_csr_device_f32", "pem_c_export_coo_f32", "pem_set_graph_replay",
     "pem_ctx_reserve", "pem_ctx_trim", "pem_ctx_memory_stats", "pem_cplan_set_option", "pem_cplan_get_option", "pem_debug_scan_i32",
+    "pem_debug_refused_launch",
 ]
 
 # enum pem_option (include/pem_spgemm.h): kernel variants / test hooks of a plan
@@ -152,6 +153,10 @@ class Context:
         _check(lib().pem_debug_scan_i32(self._h, _p(v, C.c_int32), C.c_int64(len(v)), int(regime), int(bool(in_place)), int(stall_ticket),
                                         _p(out, C.c_int32), C.byref(total)))
         return out, total.value
+
+    def debug_refused_launch(self):
+        """test hook: a kernel launch the runtime refuses; the error surfaces at the next synchronising call"""
+        _check(lib().pem_debug_refused_launch(self._h))
 
     def set_graph_replay(self, on):
         """repeat passes of CPlan.spgemm() replayed as one hipGraph (no per-step timings for those passes)"""

@@ -523,6 +523,7 @@ static pem_status derive_tiled(pem_ctx *ctx, pem_tiled *T, const int *headx, int
     T->h_tile_rowptr.assign((size_t)T->tile_rows + 1, 0);
     PEM_HIP(hipMemcpyAsync(T->h_tile_rowptr.data(), T->tile_rowptr.p, sizeof(int) * ((size_t)T->tile_rows + 1), hipMemcpyDeviceToHost, st));
     PEM_HIP(hipStreamSynchronize(st));
+    PEM_TRY(launch_status(ctx));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7]) == hipSuccess) T->conv_tile_kernel_ms = ms;
     return PEM_OK;

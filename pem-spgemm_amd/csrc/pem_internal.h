@@ -203,6 +203,8 @@ struct pem_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[3] = {};
     pem_timings timings = {};
     bool profiling = false;
+    hipError_t launch_err = hipSuccess;   // first kernel launch the runtime refused since the last report (PEM_LAUNCH)
+    const char *launch_name = nullptr;
     std::vector<pem::KernelStat> stats;
     std::vector<pem::PendingSpan> pending;
     std::vector<hipEvent_t> event_pool;
@@ -220,17 +222,31 @@ struct KernelSpan {
 };
 pem_status resolve_kernel_spans(pem_ctx *ctx);
 
+// A launch the runtime refuses (a grid beyond its limits, an invalid configuration) would otherwise go unnoticed and the pass
+// carry on with arrays nobody wrote: the first such error is kept in the context and reported -- PEM_E_HIP, with the kernel's
+// name -- by the call's next synchronisation point (pem::launch_status; read_flags does it, so does the end of every pass).
 #define PEM_LAUNCH(ctx, kernel, grid, block, ...)                                              \
     do {                                                                                       \
         pem::KernelSpan _span((ctx), #kernel);                                                 \
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__);    \
+        pem::note_launch((ctx), #kernel);                                                      \
     } while (0)
 
 #define PEM_LAUNCH_NAMED(ctx, name, kernel, grid, block, ...)                                  \
     do {                                                                                       \
         pem::KernelSpan _span((ctx), name);                                                    \
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__);    \
+        pem::note_launch((ctx), name);                                                         \
     } while (0)
+
+inline void note_launch(pem_ctx *ctx, const char *name)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess && ctx->launch_err == hipSuccess) {
+        ctx->launch_err = e;
+        ctx->launch_name = name;
+    }
+}
 
 inline unsigned grid_for(size_t n, unsigned per_block)
 {
@@ -265,6 +281,7 @@ pem_status radix_sort_u64_u32(pem_ctx *ctx, uint64_t *k0, uint64_t *k1, uint32_t
 
 pem_status zero_flags(pem_ctx *ctx);
 pem_status read_flags(pem_ctx *ctx, int *host_flags /*NUM_FLAGS*/);   // synchronises the stream
+pem_status launch_status(pem_ctx *ctx);            // PEM_E_HIP (once) if a kernel launch was refused since the last call
 pem_status check_internal(const int *host_flags);   // PEM_E_HIP if a device primitive gave up (FLAG_INTERNAL): the arrays behind it are not valid
 // copy `count` int64 scalars from device to the pinned page and synchronise
 pem_status read_scalars(pem_ctx *ctx, const int64_t *d_src, int count, int64_t *host_dst);

@@ -246,8 +246,18 @@ pem_status zero_flags(pem_ctx *ctx)
     return PEM_OK;
 }
 
+pem_status launch_status(pem_ctx *ctx)
+{
+    if (ctx->launch_err == hipSuccess) return PEM_OK;
+    set_error("kernel launch refused by the runtime: %s: %s", ctx->launch_name ? ctx->launch_name : "?", hipGetErrorString(ctx->launch_err));
+    ctx->launch_err = hipSuccess;
+    ctx->launch_name = nullptr;
+    return PEM_E_HIP;
+}
+
 pem_status read_flags(pem_ctx *ctx, int *host_flags)
 {
+    PEM_TRY(launch_status(ctx));
     int *h = reinterpret_cast<int *>(ctx->h_scalars + 48);
     PEM_HIP(hipMemcpyAsync(h, ctx->d_flags, sizeof(int) * NUM_FLAGS, hipMemcpyDeviceToHost, ctx->stream));
     PEM_HIP(hipStreamSynchronize(ctx->stream));
@@ -979,6 +989,19 @@ extern "C" pem_status pem_debug_scan_i32(pem_ctx *ctx, const int32_t *in, int64_
         pem::set_error("device scan: a block waited for an earlier ticket beyond the poll budget");
         return PEM_E_HIP;
     }
+    return PEM_OK;
+}
+
+__global__ void dbg_noop_kernel(int *flags)
+{
+    if (flags == nullptr) __builtin_trap();
+}
+// test hook (include/pem_test.h): a launch the runtime refuses must surface as PEM_E_HIP at the next synchronisation point
+extern "C" pem_status pem_debug_refused_launch(pem_ctx *ctx)
+{
+    if (!ctx) return PEM_E_INVALID;
+    PEM_ENTER(ctx);
+    PEM_LAUNCH(ctx, dbg_noop_kernel, 1, 2048, ctx->d_flags);
     return PEM_OK;
 }
 

@@ -244,6 +244,7 @@ extern "C" pem_status pem_spgemm_step1(pem_ctx *ctx, pem_cplan *plan)
     PEM_TRY(step1_impl(ctx, plan, false));   // step-wise calls always read the sizes back
     PEM_TRY(ensure_compact(ctx, plan));      // ... and leave step 1's outputs in the reference layout
     PEM_HIP(hipStreamSynchronize(ctx->stream));
+    PEM_TRY(launch_status(ctx));
     return step_elapsed(ctx, 0, 1, &ctx->timings.step1_ms);
 }
 
@@ -254,6 +255,7 @@ extern "C" pem_status pem_spgemm_step2(pem_ctx *ctx, pem_cplan *plan)
     plan->warm_pass = false;                 // step-wise calls read every size back, also after a warm pem_spgemm on this plan
     PEM_TRY(step2_impl(ctx, plan));
     PEM_HIP(hipStreamSynchronize(ctx->stream));
+    PEM_TRY(launch_status(ctx));
     return step_elapsed(ctx, 2, 3, &ctx->timings.step2_ms);
 }
 
@@ -264,6 +266,7 @@ extern "C" pem_status pem_spgemm_step3(pem_ctx *ctx, pem_cplan *plan)
     plan->warm_pass = false;
     PEM_TRY(step3_impl(ctx, plan));
     PEM_HIP(hipStreamSynchronize(ctx->stream));
+    PEM_TRY(launch_status(ctx));
     return step_elapsed(ctx, 4, 5, &ctx->timings.step3_ms);
 }
 
@@ -323,6 +326,7 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
             }
             if (!plan->graph_exec) {
                 (void)hipGetLastError();
+                ctx->launch_err = hipSuccess;   // (what failed inside the capture is retried below as plain launches)
                 plan->graph_failed = true;
             }
         }
@@ -368,6 +372,7 @@ extern "C" pem_status pem_spgemm(pem_ctx *ctx, pem_cplan *plan)
         }
     }
     PEM_HIP(hipStreamSynchronize(ctx->stream));
+    PEM_TRY(launch_status(ctx));
     plan->warm = plan->pairs_ready && plan->state == 3;
     ctx->timings.spgemm_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count();
     if (graphed) {   // a replayed graph carries no per-step events (recorded inside a capture they do not time the replay)

@@ -789,6 +789,8 @@ struct S1Row {
 // diagnostic build only (make EXTRA=-DPEM_S1_DEBUG): phase clocks of the row-sort bins, spread over 1024 slots per
 // bin so the bookkeeping atomics do not serialise; [bin][slot][pieces, load, sort, emit, rows, max row, -, -]
 __device__ unsigned long long g_s1dbg[4][1024][8];
+__device__ unsigned long long g_s1blk[4][1024][4];   // [bin][block < 1024][start, end, HW_ID, XCC_ID] of the block's first row
+extern "C" void pem_debug_s1_blocks(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s1blk), sizeof(g_s1blk)); }
 #define S1_DBG_MARK(k)                                                   \
     do {                                                                 \
         __syncthreads();                                                 \
@@ -930,29 +932,42 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
         const int nseg = (nl + 63) >> 6;
         int mytiles = 0;
 
-        for (int g = wave; g < nseg; g += WAVES) {
-            const int s = 64 * g + lane;
-            const bool valid = s < nl;
-            int j = 0;
-            int2 ab = make_int2(0, 0);
-            bool head = false;
-            if (valid) {
-                const KeyT key = keys[s];
-                const int idx = (int)(key & KeyT((1u << QB) - 1u));
-                j = (int)(key >> QB);
-                head = s == 0 || (int)(keys[s - 1] >> QB) != j;
-                const int p = np == 1 ? 0 : s1_find_a(pdst, 0, np, idx);
-                ab = lab[psrc[p] + (unsigned)(idx - pdst[p])];
+        // (four segments of the wave per trip, their (A tile, B tile) gathers in flight together: one gather per trip of this
+        // run-time loop was a chain of up to 32 memory round trips per wave in the 32768-key bin -- 15 of its 57 us)
+        for (int g0 = wave; g0 < nseg; g0 += 4 * WAVES) {
+            int jv[4];
+            int2 abv[4];
+            bool hv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int s = 64 * (g0 + u * WAVES) + lane;
+                jv[u] = 0;
+                abv[u] = make_int2(0, 0);
+                hv[u] = false;
+                if (s < nl) {
+                    const KeyT key = keys[s];
+                    const int idx = (int)(key & KeyT((1u << QB) - 1u));
+                    jv[u] = (int)(key >> QB);
+                    hv[u] = s == 0 || (int)(keys[s - 1] >> QB) != jv[u];
+                    const int p = np == 1 ? 0 : s1_find_a(pdst, 0, np, idx);
+                    abv[u] = lab[psrc[p] + (unsigned)(idx - pdst[p])];
+                }
             }
-            const unsigned long long bal = __ballot(head);
-            if (valid) {
-                pairs_a[lp0 + s] = ab.x;
-                pairs_b[lp0 + s] = ab.y;
-                pair_col[lp0 + s] = j | (head ? (int)0x80000000 : 0);
-            }
-            if (lane == 0) {
-                s1_note_heads(blk_heads, (long long)lp0 + 64 * g, bal);
-                mytiles += __popcll(bal);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + u * WAVES;
+                if (g >= nseg) break;                                        // (wave-uniform)
+                const int s = 64 * g + lane;
+                const unsigned long long bal = __ballot(hv[u]);
+                if (s < nl) {
+                    pairs_a[lp0 + s] = abv[u].x;
+                    pairs_b[lp0 + s] = abv[u].y;
+                    pair_col[lp0 + s] = jv[u] | (hv[u] ? (int)0x80000000 : 0);
+                }
+                if (lane == 0) {
+                    s1_note_heads(blk_heads, (long long)lp0 + 64 * g, bal);
+                    mytiles += __popcll(bal);
+                }
             }
         }
         // the row's C tiles
@@ -970,6 +985,15 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
         if (tid == 0) {
             atomicAdd(&g_s1dbg[DBG_BIN][blockIdx.x & 1023][4], 1ull);
             atomicMax(&g_s1dbg[DBG_BIN][blockIdx.x & 1023][5], dbg_t - dbg_row0);
+            if (li == (int)blockIdx.x && blockIdx.x < 1024) {
+                unsigned hw, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                g_s1blk[DBG_BIN][blockIdx.x][0] = dbg_row0;
+                g_s1blk[DBG_BIN][blockIdx.x][1] = dbg_t;
+                g_s1blk[DBG_BIN][blockIdx.x][2] = hw;
+                g_s1blk[DBG_BIN][blockIdx.x][3] = xcc;
+            }
         }
 #endif
         __syncthreads();                                  // the tables are rebuilt by the next row
@@ -1543,6 +1567,7 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
 {
     const pem_tiled *A = p->A;
     int *rl = p->row_list.as<int>();
+
 #define PEM_ROWSORT_ARGS(BIN, QB)                                                                                                        \
     rl + (size_t)(BIN) * mt, counts[BIN], A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->aseg.as<int2>(), p->row_lbase.as<int>(),       \
         p->live_j.as<int>(), p->live_ab.as<int2>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->pair_col.as<int>(),                   \

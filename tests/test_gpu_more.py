@@ -112,6 +112,19 @@ def test_set_option_sends_the_stepwise_api_back_to_the_last_untouched_step(pkg, 
             assert np.array_equal(g, w), opt
 
 
+def test_refused_kernel_launch_is_reported(pkg, ctx):
+    """PEM_LAUNCH (csrc/pem_internal.h): a launch the runtime refuses does not pass silently -- the next synchronising call returns
+    PEM_E_HIP and names the kernel; after the report the context works again."""
+    ctx.synchronize()
+    ctx.debug_refused_launch()                           # asynchronous: PEM_OK
+    with pytest.raises(pkg.PemError) as e:
+        ctx.synchronize()
+    assert e.value.status == -5 and "dbg_noop_kernel" in str(e.value)
+    ctx.synchronize()                                    # reported once
+    A = pkg.Tiled.from_coo(ctx, 4, 4, np.array([1], np.int32), np.array([2], np.int32), np.ones(1))
+    assert A.ntiles == 1
+
+
 def test_cli_end_to_end(pkg, oracle, standins, tmp_path):
     hostio = importlib.import_module("pem_spgemm_amd.hostio")
     rows, cols, I, J, V = standins.make("scircuit", scale=0.01)

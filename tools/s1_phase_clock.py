@@ -51,6 +51,11 @@ if os.environ.get("BLOCKS"):
         cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; xcc = x[:, 3].astype(np.int64) & 15
         place = xcc * 1000 + se * 100 + sh * 16 + cu
         print("   distinct CUs used:", len(set(place.tolist())), " XCC histogram:", np.bincount(xcc, minlength=8).tolist())
+        st = (x[:, 0].astype(np.int64) - t0) / 100.0
+        en = (x[:, 1].astype(np.int64) - t0) / 100.0
+        edges = np.arange(0, en.max() + 20, 20)
+        print("   blocks started per 20 us:", np.histogram(st, edges)[0].tolist())
+        print("   blocks running at t = 10, 30, ... us:", [int(((st <= t) & (en > t)).sum()) for t in edges[:-1] + 10])
         order = np.argsort(x[:, 0])
         for j in order[:: max(1, nb // 24)]:
             print(f"   block {j:4d} xcc {xcc[j]} se {se[j]} sh {sh[j]} cu {cu[j]:2d}  start {(int(x[j, 0]) - t0) / 100:7.1f}  dur {(int(x[j, 1]) - int(x[j, 0])) / 100:7.1f}")
