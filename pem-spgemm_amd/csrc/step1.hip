@@ -823,6 +823,177 @@ extern "C" void pem_debug_s1(unsigned long long *out32, int reset)
 // bins 1-4: one wave / 256 / 1024 / 1024 threads per tile row.  The row's pieces (one per chunk of A tiles it touches: where
 // the piece lies in the live list, where it goes in the row's list) are tabled in LDS -- one per thread, one trip -- and the
 // keys are loaded piece by piece, coalesced; the emit finds a sorted key's (A tile, B tile) through the same table.
+// one tile row of a bin: the row's pieces -> keys in LDS -> sort -> emit (the LDS arrays are the calling kernel's)
+template <typename KeyT, int CAP, int QB, int THREADS>
+__device__ __forceinline__ void s1_rowsort_row(KeyT *const keys, unsigned *const psrc, int *const pdst, int *const wsum, unsigned *const radix_hist,
+                                               const int i, const int li, const int *__restrict__ a_tile_rowptr, const int tr_lo, const int a_lo,
+                                               const int2 *__restrict__ aseg, const int *__restrict__ row_lbase, const int *__restrict__ lj,
+                                               const int2 *__restrict__ lab, int *__restrict__ pairs_a, int *__restrict__ pairs_b,
+                                               int *__restrict__ pair_col, int *__restrict__ blk_heads, int *__restrict__ row_tc, const int key_bits)
+{
+    constexpr int LOGT = THREADS == 64 ? 6 : THREADS == 256 ? 8 : 10;
+    constexpr int EMAX = CAP / THREADS, WAVES = THREADS / 64;
+    static_assert(EMAX == 8 || EMAX == 32, "a bin sorts up to 8 (or, for the largest, 32) keys per thread");
+    static_assert(CAP <= (1 << QB), "the key's index field holds every position of the row's list");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    (void)li;
+    (void)LOGT;
+#ifdef PEM_S1_DEBUG
+    constexpr int DBG_BIN = CAP == 512 ? 0 : CAP == 2048 ? 1 : CAP == 8192 ? 2 : 3;
+    unsigned long long dbg_t = 0;
+#endif
+#ifdef PEM_S1_DEBUG
+    if (tid == 0) dbg_t = wall_clock64();      // 100 MHz
+    const unsigned long long dbg_row0 = dbg_t;
+#endif
+    const int ra0 = a_tile_rowptr[tr_lo + i] - a_lo, ra1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
+    const int lp0 = row_lbase[i], nl = row_lbase[i + 1] - lp0;
+    const int c0 = ra0 / S1_CH, np = (ra1 - 1) / S1_CH - c0 + 1;       // <= THREADS: the row classification saw to that
+    {
+        unsigned src = 0;
+        int cnt = 0;
+        if (tid < np) {
+            const int c = c0 + tid;
+            const int first = ra0 > c * S1_CH ? ra0 : c * S1_CH, last = (ra1 < c * S1_CH + S1_CH ? ra1 : c * S1_CH + S1_CH) - 1;
+            const int2 s = aseg[first], e = aseg[last];
+            src = (unsigned)s.x;
+            cnt = (int)((unsigned)e.x + (unsigned)e.y - src);
+        }
+        int inc = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += o;
+        }
+        int ex = inc - cnt;
+        if (THREADS > 64 && np > 64) {               // (block-uniform) the pieces spill over the first wave
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w)
+                if (w < wave) ex += wsum[w];
+        }
+        if (tid < np) {
+            psrc[tid] = src;
+            pdst[tid] = ex;
+        }
+        if (tid == 0) pdst[np] = nl;
+    }
+    __syncthreads();
+    S1_DBG_MARK(0);
+    // the keys: (tile column, position in the row's list), list order.  Every thread takes positions of the list, finds their
+    // piece (a short search over the table; most rows have one piece) and loads from the live list: all the row's loads are
+    // independent (a wave per piece walked a 1 200-key piece of a directory row in nineteen dependent trips)
+    for (int x0 = tid; x0 < nl; x0 += 4 * THREADS) {
+        unsigned src[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int x = x0 + u * THREADS < nl ? x0 + u * THREADS : nl - 1;
+            const int p = np == 1 ? 0 : s1_find_a(pdst, 0, np, x);
+            src[u] = psrc[p] + (unsigned)(x - pdst[p]);
+        }
+        int jj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) jj[u] = lj[src[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (x0 + u * THREADS < nl) keys[x0 + u * THREADS] = (KeyT((unsigned)jj[u]) << QB) | KeyT(x0 + u * THREADS);
+    }
+    if constexpr (THREADS < 1024) {                  // the register sorts load THREADS * 2^e >= nl keys: pad
+        int upto = THREADS;
+        while (upto < nl) upto <<= 1;
+        for (int x = nl + tid; x < upto; x += THREADS) keys[x] = ~KeyT(0);
+    }
+    __syncthreads();
+    S1_DBG_MARK(1);
+    S1Row<KeyT, CAP, QB, THREADS> row;
+    row.keys = keys;
+    if constexpr (THREADS == 1024) {
+        // 16-wave bins (more than 2048 live keys): the keys sit in list order, so a STABLE radix sort on the tile
+        // column bits alone (2 passes for up to 65536 tile columns) replaces a bitonic network over the whole key
+        row.template sort_radix<EMAX>(tid, nl, radix_hist, wsum, QB, key_bits);
+    } else if (nl <= THREADS)
+        row.template sort_regs<1, LOGT>(tid);
+    else if (nl <= THREADS * 2)
+        row.template sort_regs<2, LOGT>(tid);
+    else if (nl <= THREADS * 4)
+        row.template sort_regs<4, LOGT>(tid);
+    else
+        row.template sort_regs<8, LOGT>(tid);             // a bin never holds more than CAP = THREADS * EMAX live keys
+    S1_DBG_MARK(2);
+    // Emit: one sweep over the sorted keys in segments of 64 (one wave each, round robin), no barrier -- the gathers of the
+    // pairs' (A tile, B tile) are in flight together.  A pair that opens a C tile (a new tile column) carries the mark in
+    // pair_col's sign bit; the marks per 256 pairs of the stream are counted for step 2's dense tile index.
+    const int nseg = (nl + 63) >> 6;
+    int mytiles = 0;
+
+    // (four segments of the wave per trip, their (A tile, B tile) gathers in flight together: one gather per trip of this
+    // run-time loop was a chain of up to 32 memory round trips per wave in the 32768-key bin -- 15 of its 57 us)
+    for (int g0 = wave; g0 < nseg; g0 += 4 * WAVES) {
+        int jv[4];
+        int2 abv[4];
+        bool hv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int s = 64 * (g0 + u * WAVES) + lane;
+            jv[u] = 0;
+            abv[u] = make_int2(0, 0);
+            hv[u] = false;
+            if (s < nl) {
+                const KeyT key = keys[s];
+                const int idx = (int)(key & KeyT((1u << QB) - 1u));
+                jv[u] = (int)(key >> QB);
+                hv[u] = s == 0 || (int)(keys[s - 1] >> QB) != jv[u];
+                const int p = np == 1 ? 0 : s1_find_a(pdst, 0, np, idx);
+                abv[u] = lab[psrc[p] + (unsigned)(idx - pdst[p])];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int g = g0 + u * WAVES;
+            if (g >= nseg) break;                                        // (wave-uniform)
+            const int s = 64 * g + lane;
+            const unsigned long long bal = __ballot(hv[u]);
+            if (s < nl) {
+                pairs_a[lp0 + s] = abv[u].x;
+                pairs_b[lp0 + s] = abv[u].y;
+                pair_col[lp0 + s] = jv[u] | (hv[u] ? (int)0x80000000 : 0);
+            }
+            if (lane == 0) {
+                s1_note_heads(blk_heads, (long long)lp0 + 64 * g, bal);
+                mytiles += __popcll(bal);
+            }
+        }
+    }
+    // the row's C tiles
+    int base = mytiles;
+    if constexpr (THREADS > 64) {
+        if (lane == 0) wsum[wave] = mytiles;
+        __syncthreads();
+        base = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) base += wsum[w];
+    }
+    if (tid == 0) row_tc[i] = base;
+    S1_DBG_MARK(3);
+#ifdef PEM_S1_DEBUG
+    if (tid == 0) {
+        atomicAdd(&g_s1dbg[DBG_BIN][blockIdx.x & 1023][4], 1ull);
+        atomicMax(&g_s1dbg[DBG_BIN][blockIdx.x & 1023][5], dbg_t - dbg_row0);
+        if (li == (int)blockIdx.x && blockIdx.x < 1024) {
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            g_s1blk[DBG_BIN][blockIdx.x][0] = dbg_row0;
+            g_s1blk[DBG_BIN][blockIdx.x][1] = dbg_t;
+            g_s1blk[DBG_BIN][blockIdx.x][2] = hw;
+            g_s1blk[DBG_BIN][blockIdx.x][3] = xcc;
+        }
+    }
+#endif
+    __syncthreads();                                  // the tables are rebuilt by the next row
+}
+
 template <typename KeyT, int CAP, int QB, int THREADS>
 __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || sizeof(KeyT) == 8 ? 4 : 8) : 1)
     s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr, int tr_lo, int a_lo,
@@ -830,174 +1001,39 @@ __global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || size
                       int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ pair_col, int *__restrict__ blk_heads,
                       int *__restrict__ row_tc, int key_bits)
 {
-    constexpr int LOGT = THREADS == 64 ? 6 : THREADS == 256 ? 8 : 10;
-    constexpr int EMAX = CAP / THREADS, WAVES = THREADS / 64;
-    static_assert(EMAX == 8 || EMAX == 32, "a bin sorts up to 8 (or, for the largest, 32) keys per thread");
-    static_assert(CAP <= (1 << QB), "the key's index field holds every position of the row's list");
     __shared__ KeyT keys[CAP];
     __shared__ unsigned psrc[THREADS];   // piece p of the row: where it lies in the live list ...
     __shared__ int pdst[THREADS + 1];    // ... and where it goes in the row's list (exclusive scan of the piece lengths)
-    __shared__ int wsum[WAVES];
-    __shared__ unsigned radix_hist[THREADS == 1024 ? WAVES * 256 : 1];   // digit counters of the radix sort (16-wave bins)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    (void)0;
-#ifdef PEM_S1_DEBUG
-    constexpr int DBG_BIN = CAP == 512 ? 0 : CAP == 2048 ? 1 : CAP == 8192 ? 2 : 3;
-    unsigned long long dbg_t = 0;
-#endif
-    for (int li = blockIdx.x; li < nrows_bin; li += gridDim.x) {
-        const int i = row_list[li];
-#ifdef PEM_S1_DEBUG
-        if (tid == 0) dbg_t = wall_clock64();      // 100 MHz
-        const unsigned long long dbg_row0 = dbg_t;
-#endif
-        const int ra0 = a_tile_rowptr[tr_lo + i] - a_lo, ra1 = a_tile_rowptr[tr_lo + i + 1] - a_lo;
-        const int lp0 = row_lbase[i], nl = row_lbase[i + 1] - lp0;
-        const int c0 = ra0 / S1_CH, np = (ra1 - 1) / S1_CH - c0 + 1;       // <= THREADS: the row classification saw to that
-        {
-            unsigned src = 0;
-            int cnt = 0;
-            if (tid < np) {
-                const int c = c0 + tid;
-                const int first = ra0 > c * S1_CH ? ra0 : c * S1_CH, last = (ra1 < c * S1_CH + S1_CH ? ra1 : c * S1_CH + S1_CH) - 1;
-                const int2 s = aseg[first], e = aseg[last];
-                src = (unsigned)s.x;
-                cnt = (int)((unsigned)e.x + (unsigned)e.y - src);
-            }
-            int inc = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_up(inc, d, 64);
-                if (lane >= d) inc += o;
-            }
-            int ex = inc - cnt;
-            if (THREADS > 64 && np > 64) {               // (block-uniform) the pieces spill over the first wave
-                if (lane == 63) wsum[wave] = inc;
-                __syncthreads();
-#pragma unroll
-                for (int w = 0; w < WAVES; ++w)
-                    if (w < wave) ex += wsum[w];
-            }
-            if (tid < np) {
-                psrc[tid] = src;
-                pdst[tid] = ex;
-            }
-            if (tid == 0) pdst[np] = nl;
-        }
-        __syncthreads();
-        S1_DBG_MARK(0);
-        // the keys: (tile column, position in the row's list), list order.  Every thread takes positions of the list, finds their
-        // piece (a short search over the table; most rows have one piece) and loads from the live list: all the row's loads are
-        // independent (a wave per piece walked a 1 200-key piece of a directory row in nineteen dependent trips)
-        for (int x0 = tid; x0 < nl; x0 += 4 * THREADS) {
-            unsigned src[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int x = x0 + u * THREADS < nl ? x0 + u * THREADS : nl - 1;
-                const int p = np == 1 ? 0 : s1_find_a(pdst, 0, np, x);
-                src[u] = psrc[p] + (unsigned)(x - pdst[p]);
-            }
-            int jj[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) jj[u] = lj[src[u]];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (x0 + u * THREADS < nl) keys[x0 + u * THREADS] = (KeyT((unsigned)jj[u]) << QB) | KeyT(x0 + u * THREADS);
-        }
-        if constexpr (THREADS < 1024) {                  // the register sorts load THREADS * 2^e >= nl keys: pad
-            int upto = THREADS;
-            while (upto < nl) upto <<= 1;
-            for (int x = nl + tid; x < upto; x += THREADS) keys[x] = ~KeyT(0);
-        }
-        __syncthreads();
-        S1_DBG_MARK(1);
-        S1Row<KeyT, CAP, QB, THREADS> row;
-        row.keys = keys;
-        if constexpr (THREADS == 1024) {
-            // 16-wave bins (more than 2048 live keys): the keys sit in list order, so a STABLE radix sort on the tile
-            // column bits alone (2 passes for up to 65536 tile columns) replaces a bitonic network over the whole key
-            row.template sort_radix<EMAX>(tid, nl, radix_hist, wsum, QB, key_bits);
-        } else if (nl <= THREADS)
-            row.template sort_regs<1, LOGT>(tid);
-        else if (nl <= THREADS * 2)
-            row.template sort_regs<2, LOGT>(tid);
-        else if (nl <= THREADS * 4)
-            row.template sort_regs<4, LOGT>(tid);
-        else
-            row.template sort_regs<8, LOGT>(tid);             // a bin never holds more than CAP = THREADS * EMAX live keys
-        S1_DBG_MARK(2);
-        // Emit: one sweep over the sorted keys in segments of 64 (one wave each, round robin), no barrier -- the gathers of the
-        // pairs' (A tile, B tile) are in flight together.  A pair that opens a C tile (a new tile column) carries the mark in
-        // pair_col's sign bit; the marks per 256 pairs of the stream are counted for step 2's dense tile index.
-        const int nseg = (nl + 63) >> 6;
-        int mytiles = 0;
+    __shared__ int wsum[THREADS / 64];
+    __shared__ unsigned radix_hist[THREADS == 1024 ? (THREADS / 64) * 256 : 1];   // digit counters of the radix sort (16-wave bins)
+    for (int li = blockIdx.x; li < nrows_bin; li += gridDim.x)
+        s1_rowsort_row<KeyT, CAP, QB, THREADS>(keys, psrc, pdst, wsum, radix_hist, row_list[li], li, a_tile_rowptr, tr_lo, a_lo, aseg, row_lbase, lj, lab,
+                                               pairs_a, pairs_b, pair_col, blk_heads, row_tc, key_bits);
+}
 
-        // (four segments of the wave per trip, their (A tile, B tile) gathers in flight together: one gather per trip of this
-        // run-time loop was a chain of up to 32 memory round trips per wave in the 32768-key bin -- 15 of its 57 us)
-        for (int g0 = wave; g0 < nseg; g0 += 4 * WAVES) {
-            int jv[4];
-            int2 abv[4];
-            bool hv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int s = 64 * (g0 + u * WAVES) + lane;
-                jv[u] = 0;
-                abv[u] = make_int2(0, 0);
-                hv[u] = false;
-                if (s < nl) {
-                    const KeyT key = keys[s];
-                    const int idx = (int)(key & KeyT((1u << QB) - 1u));
-                    jv[u] = (int)(key >> QB);
-                    hv[u] = s == 0 || (int)(keys[s - 1] >> QB) != jv[u];
-                    const int p = np == 1 ? 0 : s1_find_a(pdst, 0, np, idx);
-                    abv[u] = lab[psrc[p] + (unsigned)(idx - pdst[p])];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int g = g0 + u * WAVES;
-                if (g >= nseg) break;                                        // (wave-uniform)
-                const int s = 64 * g + lane;
-                const unsigned long long bal = __ballot(hv[u]);
-                if (s < nl) {
-                    pairs_a[lp0 + s] = abv[u].x;
-                    pairs_b[lp0 + s] = abv[u].y;
-                    pair_col[lp0 + s] = jv[u] | (hv[u] ? (int)0x80000000 : 0);
-                }
-                if (lane == 0) {
-                    s1_note_heads(blk_heads, (long long)lp0 + 64 * g, bal);
-                    mytiles += __popcll(bal);
-                }
-            }
-        }
-        // the row's C tiles
-        int base = mytiles;
-        if constexpr (THREADS > 64) {
-            if (lane == 0) wsum[wave] = mytiles;
-            __syncthreads();
-            base = 0;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) base += wsum[w];
-        }
-        if (tid == 0) row_tc[i] = base;
-        S1_DBG_MARK(3);
-#ifdef PEM_S1_DEBUG
-        if (tid == 0) {
-            atomicAdd(&g_s1dbg[DBG_BIN][blockIdx.x & 1023][4], 1ull);
-            atomicMax(&g_s1dbg[DBG_BIN][blockIdx.x & 1023][5], dbg_t - dbg_row0);
-            if (li == (int)blockIdx.x && blockIdx.x < 1024) {
-                unsigned hw, xcc;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                g_s1blk[DBG_BIN][blockIdx.x][0] = dbg_row0;
-                g_s1blk[DBG_BIN][blockIdx.x][1] = dbg_t;
-                g_s1blk[DBG_BIN][blockIdx.x][2] = hw;
-                g_s1blk[DBG_BIN][blockIdx.x][3] = xcc;
-            }
-        }
-#endif
-        __syncthreads();                                  // the tables are rebuilt by the next row
-    }
+// The two sixteen-wave bins in ONE launch (32-bit keys; few rows in either): the first n4 workgroups take the rows of the
+// 32768-key bin, the others those of the 8192-key bin.  As two kernels one of them sat on an auxiliary stream, whose work starts
+// 15-20 us after the main stream's in a replayed graph (cross-queue dependency) -- and both are ~57 us of one workgroup's
+// latency on the webbase-1M stand-in, so that delay was on the critical path of step 1.  The LDS is the large bin's (one
+// workgroup per CU), hence only where the 8192-key bin holds no more rows than there are CUs.
+__global__ void __launch_bounds__(1024, 4)
+    s1_rowsort_big_kernel(const int *__restrict__ list4, int n4, const int *__restrict__ list3, int n3, const int *__restrict__ a_tile_rowptr, int tr_lo,
+                          int a_lo, const int2 *__restrict__ aseg, const int *__restrict__ row_lbase, const int *__restrict__ lj,
+                          const int2 *__restrict__ lab, int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ pair_col,
+                          int *__restrict__ blk_heads, int *__restrict__ row_tc, int key_bits4, int key_bits3)
+{
+    __shared__ uint32_t keys[S1_CAP4];
+    __shared__ unsigned psrc[1024];
+    __shared__ int pdst[1024 + 1];
+    __shared__ int wsum[16];
+    __shared__ unsigned radix_hist[16 * 256];
+    const int b = blockIdx.x;
+    if (b < n4)
+        s1_rowsort_row<uint32_t, S1_CAP4, S1_QB4, 1024>(keys, psrc, pdst, wsum, radix_hist, list4[b], b, a_tile_rowptr, tr_lo, a_lo, aseg, row_lbase, lj, lab,
+                                                        pairs_a, pairs_b, pair_col, blk_heads, row_tc, key_bits4);
+    else if (b - n4 < n3)
+        s1_rowsort_row<uint32_t, S1_CAP3, S1_QB3, 1024>(keys, psrc, pdst, wsum, radix_hist, list3[b - n4], b - n4, a_tile_rowptr, tr_lo, a_lo, aseg, row_lbase,
+                                                        lj, lab, pairs_a, pairs_b, pair_col, blk_heads, row_tc, key_bits3);
 }
 
 // Big rows in column-range segments.  A row of more than 8192 live products sorted by ONE workgroup is a serial chain of 50-300
@@ -1581,6 +1617,9 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
             PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<" #CAP ",key64>", (s1_rowsort_kernel<uint64_t, CAP, QB, THREADS>), counts[BIN],      \
                              THREADS, PEM_ROWSORT_ARGS(BIN, QB));                                                                        \
     } while (0)
+    const int ncu = ctx->cu_count > 0 ? ctx->cu_count : 256;
+    const bool merge_big = !p->opt_s1_segments && !p->opt_s1_serial && counts[4] > 0 && counts[3] > 0 && counts[3] + counts[4] <= ncu &&
+                           bits_tc + S1_QB4 <= 32 && !force64;
     if (p->opt_s1_segments) {
         if (nsegs > 0) {                   // rows above the 8192-key bin, one workgroup per column-range segment
             lanes.on(0);
@@ -1595,12 +1634,18 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
                                  p->live_ab.as<int2>(), p->B->tile_cols, p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->pair_col.as<int>(),
                                  p->blk_heads.as<int>(), p->c_tile_rowptr.as<int>());
         }
+    } else if (merge_big) {                // both sixteen-wave bins, few rows each: one launch on the main stream (see the kernel)
+        lanes.on(0);
+        PEM_LAUNCH_NAMED(ctx, "s1_rowsort_big_kernel", s1_rowsort_big_kernel, counts[4] + counts[3], 1024, rl + (size_t)4 * mt, counts[4],
+                         rl + (size_t)3 * mt, counts[3], A->tile_rowptr.as<int>(), p->tr_lo, p->a_lo, p->aseg.as<int2>(), p->row_lbase.as<int>(),
+                         p->live_j.as<int>(), p->live_ab.as<int2>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(), p->pair_col.as<int>(),
+                         p->blk_heads.as<int>(), p->c_tile_rowptr.as<int>(), S1_QB4 + bits_tc, S1_QB3 + bits_tc);
     } else if (counts[4] > 0) {            // (only populated where 32-bit keys hold a 15-bit index: see the row classification's cap4)
         lanes.on(0);
         PEM_LAUNCH_NAMED(ctx, "s1_rowsort_kernel<32768>", (s1_rowsort_kernel<uint32_t, S1_CAP4, S1_QB4, 1024>), counts[4], 1024,
                          PEM_ROWSORT_ARGS(4, S1_QB4));
     }
-    if (counts[3] > 0) {
+    if (counts[3] > 0 && !merge_big) {
         lanes.on(2);
         PEM_ROWSORT(3, 8192, S1_QB3, 1024);
     }
@@ -1615,7 +1660,7 @@ static void launch_rowsorts(pem_ctx *ctx, pem_cplan *p, S1Lanes &lanes, const in
                    p->blk_heads.as<int>(), p->c_tile_rowptr.as<int>());
     }
     if (counts[1] > 0) {
-        lanes.on(1);
+        lanes.on(merge_big ? 2 : 1);       // (the 8192-key bin's stream is free then: the one-wave bins run beside each other)
         PEM_ROWSORT(1, 512, S1_QB1, 64);
     }
     lanes.on(0);
