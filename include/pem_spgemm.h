@@ -168,7 +168,7 @@ typedef enum {
     PEM_OPT_S3_BAND = 4,            /* 1 (default): many-pair C tiles of deep plans go to the wave-per-tile kernel              */
     PEM_OPT_EXPORT_ROWS = 7,        /* 0 (default): balanced chunk export; 1: 16 lanes per tile row (A/B baseline)             */
     PEM_OPT__TEST_FIRST = 5,        /* (5, 6, 8-15: pem_test.h)                                                                 */
-    PEM_OPT__LAST = 15
+    PEM_OPT__LAST = 16
 } pem_option;
 pem_status pem_cplan_set_option(pem_cplan *plan, pem_option which, int64_t value);
 pem_status pem_cplan_get_option(const pem_cplan *plan, pem_option which, int64_t *value);

@@ -28,6 +28,9 @@ extern "C" {
 #define PEM_OPT_S1_SEGMENTS    ((pem_option)15) /* 0 (default): one workgroup per tile row above the 8192-key bin; 1: such rows are sorted in
                                                    column-range segments, one workgroup per segment -- pays where a plan holds a handful of
                                                    them (webbase-1M's directory rows in a 1/8 row block), costs where it holds hundreds         */
+#define PEM_OPT_S2_TRANSPOSED  ((pem_option)16) /* step 2's boolean tile product: 0 from A's row masks (one trip per nonzero of the A tile), 1 from A's
+                                                   transposed masks (one trip per inner index occupied on both sides), 2 (default): 1 on repeat
+                                                   passes of plans with two or more pairs per C tile (cage15-class), else 0            */
 
 /* The device exclusive scan (replaces thrust::exclusive_scan, spgemm.cu:1168, 1242, 1288, and NSPARSE/utils_cuda_scan.h)
  * on a caller's array: out[0..n] = exclusive prefix sums, out[n] = *total.  regime 0: chosen by n like the hot path;

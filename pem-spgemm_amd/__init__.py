@@ -42,7 +42,7 @@ ABI_SYMBOLS = [
 ]
 
 # enum pem_option (include/pem_spgemm.h): kernel variants / test hooks of a plan
-OPTIONS = dict(prune=0, step1_global_sort=1, wide=2, warm=3, s3_band=4, s1_force_key64=5, s1_xlcap=6, export_rows=7, s1_serial=8, s3_decode=9, s1_xl_global=10, s3_epw=11, s3_idx64=12, s3_mark=13, s3_xcd=14, s1_segments=15)
+OPTIONS = dict(prune=0, step1_global_sort=1, wide=2, warm=3, s3_band=4, s1_force_key64=5, s1_xlcap=6, export_rows=7, s1_serial=8, s3_decode=9, s1_xl_global=10, s3_epw=11, s3_idx64=12, s3_mark=13, s3_xcd=14, s1_segments=15, s2_transposed=16)
 
 
 class PemError(RuntimeError):

@@ -370,6 +370,7 @@ struct pem_cplan {
     int w_counts[5] = {0, 0, 0, 0, 0};
     int w_nsegs = 0;                   // column-range segments of the big rows (s1_rowseg_kernel)
     pem::DevBuf seg_list;              // int2 per segment: (tile row, segment | segments of the row << 16)
+    int opt_s2_transposed = 2;         // step 2's tile product from A's transposed masks: 0 never, 1 always, 2 on repeat passes of deep plans (see s2_pair_mask_t)
     int opt_s1_segments = 0;           // 1: rows above the 8192-key bin are sorted in column-range segments, one workgroup each (off by default: see s1_rowseg_kernel)
     int64_t w_nxl = 0;
     int w_nrows_xl = 0, w_max_xl = 0;

@@ -167,6 +167,7 @@ static int *plan_option_slot(pem_cplan *p, pem_option which)
     case PEM_OPT_S3_IDX64: return &p->opt_idx64;
     case PEM_OPT_S3_MARK: return &p->opt_mark;
     case PEM_OPT_S1_SEGMENTS: return &p->opt_s1_segments;
+    case PEM_OPT_S2_TRANSPOSED: return &p->opt_s2_transposed;
     default: return nullptr;
     }
 }
@@ -179,7 +180,7 @@ extern "C" pem_status pem_cplan_set_option(pem_cplan *plan, pem_option which, in
         set_error("pem_cplan_set_option: unknown option %d or value %lld out of range", (int)which, (long long)value);
         return PEM_E_INVALID;
     }
-    const int v = (which == PEM_OPT_S1_XLCAP || which == PEM_OPT_S3_EPW) ? (int)value : (value != 0);
+    const int v = (which == PEM_OPT_S1_XLCAP || which == PEM_OPT_S3_EPW || which == PEM_OPT_S2_TRANSPOSED) ? (int)value : (value != 0);
     if (*slot == v) return PEM_OK;
     *slot = v;
     // a repeat pass re-uses the sizes (and possibly the captured graph) of the previous one: whatever changes the kernels
@@ -192,7 +193,7 @@ extern "C" pem_status pem_cplan_set_option(pem_cplan *plan, pem_option which, in
     switch ((int)which) {
     case PEM_OPT_PRUNE: case PEM_OPT_STEP1_GLOBAL_SORT: case PEM_OPT_S1_FORCE_KEY64: case PEM_OPT_S1_XLCAP: case PEM_OPT_S1_XL_GLOBAL:
     case PEM_OPT_S1_SEGMENTS: keep = 0; break;
-    case PEM_OPT_WIDE: case PEM_OPT_S3_DECODE: keep = 1; break;
+    case PEM_OPT_WIDE: case PEM_OPT_S3_DECODE: case PEM_OPT_S2_TRANSPOSED: keep = 1; break;
     case PEM_OPT_S3_BAND: case PEM_OPT_S3_EPW: case PEM_OPT_S3_IDX64: case PEM_OPT_S3_MARK: case PEM_OPT_S3_XCD: keep = 2; break;
     default: break;                                    // warm passes, the export variant, serial bins: no step's result changes
     }

@@ -121,6 +121,33 @@ __device__ __forceinline__ void s2_pair_mask(const S2Masks &m, unsigned (*bl)[25
     }
 }
 
+// The same product from A's TRANSPOSED masks (column k of the A tile = the rows that hold it): C[r] |= B[k] for every row r in
+// column k -- iterated over the inner indices k that are occupied on BOTH sides (A's occupied columns & B's occupied rows: one to
+// three for most pairs, it is what step 1's pruning tested), each spread over the eight row-pair words by bit-field ops with no
+// branch.  The row-major form above walks every nonzero of the A tile, at the pace of the wave's densest row pair; this one does
+// popcount(live) trips of ~40 vector-ALU instructions (s2_tiles_kernel was bound by them: 786 per 64 pairs).
+__device__ __forceinline__ void s2_pair_mask_t(const uint4 T0, const uint4 T1, const uint4 B0, const uint4 B1, unsigned live, unsigned (*bl)[256],
+                                               const int tid, unsigned (&cw)[8])
+{
+    bl[0][tid] = B0.x; bl[1][tid] = B0.y; bl[2][tid] = B0.z; bl[3][tid] = B0.w;
+    bl[4][tid] = B1.x; bl[5][tid] = B1.y; bl[6][tid] = B1.z; bl[7][tid] = B1.w;
+    bl[8][tid] = T0.x; bl[9][tid] = T0.y; bl[10][tid] = T0.z; bl[11][tid] = T0.w;
+    bl[12][tid] = T1.x; bl[13][tid] = T1.y; bl[14][tid] = T1.z; bl[15][tid] = T1.w;
+    while (live) {
+        const int k = __builtin_ctz(live);
+        live &= live - 1;
+        const unsigned bwd = bl[k >> 1][tid], twd = bl[8 + (k >> 1)][tid];
+        const unsigned brow = (k & 1) ? (bwd >> 16) : (bwd & 0xFFFFu);     // B's row k
+        const int cm = (int)((k & 1) ? (twd >> 16) : (twd & 0xFFFFu));      // the rows of the A tile that hold column k
+        const unsigned bb = brow | (brow << 16);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_sbfe(cm, 2 * q, 1), hi = (unsigned)__builtin_amdgcn_sbfe(cm, 2 * q + 1, 1);   // 0 or ~0
+            cw[q] |= bb & ((lo & 0xFFFFu) | (hi & 0xFFFF0000u));
+        }
+    }
+}
+
 // (r<<4|c) bytes of one C tile from its masks in the natural layout (a12, spgemm.cu:582-587), row-major
 __device__ __forceinline__ void s2_emit_rowcol(const unsigned (&cw)[8], uint8_t *__restrict__ dst)
 {
@@ -176,13 +203,15 @@ __device__ __forceinline__ unsigned s2_wave_shl1(unsigned v)   // lane i <- lane
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true);
 }
 
-__global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ pair_col, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b,
+template <bool TRANSPOSED>
+__global__ void __launch_bounds__(256, 8) s2_tiles_kernel(const int *__restrict__ pair_col, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b,
                                                        long long npairs, const int *__restrict__ blk_base,
-                                                       const uint16_t *__restrict__ a_masks, const uint16_t *__restrict__ b_masks, long long ntc,
+                                                       const uint16_t *__restrict__ a_masks_t, const uint16_t *__restrict__ b_masks,
+                                                       const uint32_t *__restrict__ a_occ, const uint32_t *__restrict__ b_occ, long long ntc,
                                                        int *__restrict__ c_colidx, int *__restrict__ pairs_offset, uint32_t *__restrict__ c_mask,
                                                        int *__restrict__ group_nnz, uint16_t *__restrict__ c_cnt)
 {
-    __shared__ unsigned bl[8][256];
+    __shared__ unsigned bl[TRANSPOSED ? 16 : 8][256];
     const int tid = threadIdx.x, lane = tid & 63;
     const long long w = (long long)blockIdx.x * 4 + (tid >> 6);          // the wave's 256 pairs
     const long long p_lo = w * 256;
@@ -224,8 +253,15 @@ __global__ void __launch_bounds__(256) s2_tiles_kernel(const int *__restrict__ p
         const bool mine = valid && (lane < f ? open : !over);
         unsigned cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // natural layout: cw[q] = row 2q | row 2q+1 << 16
         if (mine) {
-            const S2Masks m = s2_load_masks(a_masks, b_masks, ida, idb);
-            s2_pair_mask(m, bl, tid, cw);
+            if constexpr (TRANSPOSED) {   // (a_masks_t = A's transposed masks)
+                const uint4 T0 = *reinterpret_cast<const uint4 *>(a_masks_t + 16 * (size_t)ida), T1 = *reinterpret_cast<const uint4 *>(a_masks_t + 16 * (size_t)ida + 8);
+                const uint4 B0 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)idb), B1 = *reinterpret_cast<const uint4 *>(b_masks + 16 * (size_t)idb + 8);
+                const unsigned live = (a_occ[ida] & 0xFFFFu) & (b_occ[idb] >> 16);
+                s2_pair_mask_t(T0, T1, B0, B1, live, bl, tid, cw);
+            } else {                      // (a_masks_t = A's row masks)
+                const S2Masks m = s2_load_masks(a_masks_t, b_masks, ida, idb);
+                s2_pair_mask(m, bl, tid, cw);
+            }
         }
         // OR toward the first pair of every tile: lane i absorbs lane i + 1 while lane i + 1 is a further pair of the same tile
         const unsigned long long N = __ballot(mine && !head);            // absorbed lanes
@@ -494,10 +530,22 @@ pem_status pem::step2_impl(pem_ctx *ctx, pem_cplan *p)
             const bool decode = p->opt_decode && !deep;
             p->s3_decode = decode;
             if (decode) PEM_TRY(p->c_tile_cnt.reserve(sizeof(uint16_t) * (ntc + 8)));
-            PEM_LAUNCH(ctx, s2_tiles_kernel, (unsigned)((n + 1023) / 1024), 256, p->pair_col.as<int>(), p->pairs_a.as<int>(), p->pairs_b.as<int>(),
-                       (long long)n, p->blk_heads.as<int>(), A->masks.as<uint16_t>(), B->masks.as<uint16_t>(), (long long)ntc,
-                       p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>(), p->c_mask.as<uint32_t>(), group_nnz,
-                       decode ? p->c_tile_cnt.as<uint16_t>() : (uint16_t *)nullptr);
+            // the tile product from A's transposed masks pays on cage15-class plans (1/8 share: step 2 2.29 -> 1.66 ms) and costs on
+            // the sparse ones (r2 stand-in 0.39 -> 0.46 ms, scircuit 0.077 -> 0.093: two more gathers per pair): by default on the
+            // repeat passes of plans with two or more pairs per C tile, whose sizes the pass before left
+            const bool transposed = p->opt_s2_transposed == 1 || (p->opt_s2_transposed == 2 && p->warm_pass && p->w_P >= 2 * p->w_TC);
+            if (transposed)
+                PEM_LAUNCH_NAMED(ctx, "s2_tiles_kernel<transposed>", s2_tiles_kernel<true>, (unsigned)((n + 1023) / 1024), 256, p->pair_col.as<int>(),
+                                 p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)n, p->blk_heads.as<int>(), A->masks_t.as<uint16_t>(),
+                                 B->masks.as<uint16_t>(), A->tile_occ.as<uint32_t>(), B->tile_occ.as<uint32_t>(), (long long)ntc,
+                                 p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>(), p->c_mask.as<uint32_t>(), group_nnz,
+                                 decode ? p->c_tile_cnt.as<uint16_t>() : (uint16_t *)nullptr);
+            else
+                PEM_LAUNCH_NAMED(ctx, "s2_tiles_kernel", s2_tiles_kernel<false>, (unsigned)((n + 1023) / 1024), 256, p->pair_col.as<int>(),
+                                 p->pairs_a.as<int>(), p->pairs_b.as<int>(), (long long)n, p->blk_heads.as<int>(), A->masks.as<uint16_t>(),
+                                 B->masks.as<uint16_t>(), A->tile_occ.as<uint32_t>(), B->tile_occ.as<uint32_t>(), (long long)ntc,
+                                 p->c_tile_colidx.as<int>(), p->pairs_offset.as<int>(), p->c_mask.as<uint32_t>(), group_nnz,
+                                 decode ? p->c_tile_cnt.as<uint16_t>() : (uint16_t *)nullptr);
             PEM_TRY(exclusive_scan_i32(ctx, group_nnz, group_nnz, ngroups, ctx->d_scalars + 2));
             if (p->warm_pass) {
                 nnzc = p->w_nnz;

@@ -536,7 +536,7 @@ __global__ void __launch_bounds__(256) s3_band_kernel(const int *__restrict__ pa
                     }
                 }
             }
-            if (mine) c_vals[e] = acc;
+            if (mine) __builtin_nontemporal_store(acc, c_vals + e);   // (never re-read here: keep the L2 for the operand records and values)
         }
     }
 }

@@ -140,7 +140,9 @@ def test_plan_options_through_the_abi(pkg, oracle, ctx):
                                ({"step1_global_sort": 0, "prune": 0}, unpruned, unpruned_counts),
                                ({"prune": 1, "s1_xlcap": 40}, pruned, pruned_counts), ({"s1_xlcap": 0, "s1_force_key64": 1}, pruned, pruned_counts),
                                ({"s1_force_key64": 0, "warm": 0}, pruned, pruned_counts), ({"warm": 1, "s1_segments": 1}, pruned, pruned_counts),
-                               ({"s1_segments": 0}, pruned, pruned_counts)):
+                               ({"s1_segments": 0}, pruned, pruned_counts), ({"s2_transposed": 1}, pruned, pruned_counts),
+                               ({"prune": 0}, unpruned, unpruned_counts), ({"prune": 1, "s2_transposed": 0}, pruned, pruned_counts),
+                               ({"s2_transposed": 2}, pruned, pruned_counts)):
         for k, v in opts.items():
             plan.set_option(k, v)
             assert plan.get_option(k) == v
@@ -152,6 +154,26 @@ def test_plan_options_through_the_abi(pkg, oracle, ctx):
                 assert np.array_equal(plan.array(arr), want[arr]), f"{opts}: {arr} differs"
     with pytest.raises(pkg.PemError):
         pkg._check(pkg.lib().pem_cplan_set_option(plan._h, 99, pkg.C.c_int64(1)))
+
+
+@pytest.mark.parametrize("name", ["powerlaw_600", "hub_row_4000", "dense_48", "dense_tile", "ragged_37", "empty_rows", "banded_500_AAt", "rect_70x40_AAt",
+                                  "rect_33x65_AAt", "cancel_and_zero", "band_1500"])
+def test_step2_tile_product_from_transposed_masks(pkg, oracle, ctx, name):
+    """PEM_OPT_S2_TRANSPOSED (include/pem_test.h): the boolean tile product C[r] |= B[k] taken column by column of the A tile -- over
+    the inner indices occupied on both sides -- instead of nonzero by nonzero of its rows (spgemm.cu:499-550).  Every C array must
+    equal the oracle's either way, pruned lists and the reference's own (where pairs with no common inner index give empty masks)."""
+    gA, gB, oA, oB = _pair(pkg, oracle, ctx, CASES[name])
+    op = oracle.Plan(oA, oB)
+    plan = pkg.CPlan(ctx, gA, gB)
+    for prune in (1, 0):
+        want, counts = expected(op, oA, oB, bool(prune))
+        plan.set_option("prune", prune)
+        for tr in (1, 0):
+            plan.set_option("s2_transposed", tr)
+            for _ in range(2):
+                plan.spgemm()
+                for arr in C_NAMES:
+                    assert np.array_equal(plan.array(arr), want[arr]), f"prune {prune} transposed {tr}: {arr} differs"
 
 
 @pytest.mark.parametrize("name", ["powerlaw_600", "hub_row_4000", "dense_48", "dense_tile", "ragged_37", "empty_rows", "blockrows_1600", "rect_70x40_AAt"])
