@@ -10,9 +10,10 @@
 // a row's products by j yields the C tile list (step 1) and the pair lists in ascending k (step 2a/2b) in one
 // pass -- no SPA, no hash tables, no binary searches, nothing computed twice.  Products whose tiles cannot
 // meet (A tile's occupied columns miss B tile's occupied rows) are dropped up front (exact; PEM_PRUNE=0 keeps
-// the reference's lists).  Default path: per-row LDS/register bitonic sorts, binned by row size; the global
-// expand + radix-sort path ("esc") serves oversized rows and PEM_STEP1=esc.  Step 2c is the boolean row
-// product (C row r = OR of B rows kk over kk in A row r), one C tile per lane; step 3 keeps one C entry per
+// the reference's lists).  Default path (round 4): one kernel forms and tests every product once and leaves the live ones in a
+// list; per-row sorts of that list (registers / LDS bitonic / LDS radix), binned by row size, emit the pair lists; the global
+// expand + radix-sort path ("esc") is kept as PEM_STEP1=esc.  Step 2c is the boolean row product (C row r = OR of B rows kk
+// over kk in A row r), one PAIR per lane with a segmented OR toward the C tile's first pair; step 3 keeps one C entry per
 // lane in a register, accumulates in ascending k with one fma per product, and stores once.  All outputs keep
 // the reference layouts (include/pem_spgemm.h).  Kernel variants (A/B baselines kept for tests) are plan options
 // (pem_cplan_set_option); the environment only sets a new plan's defaults:

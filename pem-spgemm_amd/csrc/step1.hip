@@ -219,7 +219,7 @@ __device__ __forceinline__ int s1_wave_inclusive_scan_dpp(int v)
     return v;
 }
 
-__global__ void __launch_bounds__(64 * S1_XW) s1_expand_kernel(const int *__restrict__ a_tile_colidx, const uint32_t *__restrict__ a_occ, int a_lo, int nA,
+__global__ void __launch_bounds__(64 * S1_XW, 8) s1_expand_kernel(const int *__restrict__ a_tile_colidx, const uint32_t *__restrict__ a_occ, int a_lo, int nA,
                                                                const int *__restrict__ b_tile_rowptr, const int2 *__restrict__ b_colocc, int prune,
                                                                int *__restrict__ bin_count, unsigned long long cap, int2 *__restrict__ aseg,
                                                                int2 *__restrict__ chunk_seg, long long *__restrict__ chunk_n, int *__restrict__ lj,
@@ -995,7 +995,7 @@ __device__ __forceinline__ void s1_rowsort_row(KeyT *const keys, unsigned *const
 }
 
 template <typename KeyT, int CAP, int QB, int THREADS>
-__global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || sizeof(KeyT) == 8 ? 4 : 8) : 1)
+__global__ void __launch_bounds__(THREADS, THREADS == 1024 ? (CAP > 8192 || sizeof(KeyT) == 8 ? 4 : 8) : (sizeof(KeyT) == 8 ? 1 : 8))
     s1_rowsort_kernel(const int *__restrict__ row_list, int nrows_bin, const int *__restrict__ a_tile_rowptr, int tr_lo, int a_lo,
                       const int2 *__restrict__ aseg, const int *__restrict__ row_lbase, const int *__restrict__ lj, const int2 *__restrict__ lab,
                       int *__restrict__ pairs_a, int *__restrict__ pairs_b, int *__restrict__ pair_col, int *__restrict__ blk_heads,

@@ -79,7 +79,10 @@ template <bool IDX32, typename T> __device__ __forceinline__ T s3_ld(const T *__
 // 64-word LDS strip, one ballot turns the strip into a bit mask, and an entry's tile is (tiles started before the trip) +
 // (marks at or below its lane) - 1.
 template <typename VT, bool DEEP, bool BAND = false, bool DECODE = false, bool IDX32 = false, bool MARK = false>
-__global__ void __launch_bounds__(256, DEEP ? 1 : 8) s3_accumulate_wide_kernel(
+#ifndef PEM_S3_DEEP_WAVES
+#define PEM_S3_DEEP_WAVES 1   // (8 = at most 64 VGPRs for the deep variants too: 6 of them spill and a cage15 share's step 3 is 6.83 against 6.74 ms)
+#endif
+__global__ void __launch_bounds__(256, DEEP ? PEM_S3_DEEP_WAVES : 8) s3_accumulate_wide_kernel(
     const int *__restrict__ pairs_offset, const int *__restrict__ pairs_a, const int *__restrict__ pairs_b, long long ntc,
     const int *__restrict__ c_tile_nnz_ptr, long long nnz_c, const uint8_t *__restrict__ c_rowcolidx, VT *__restrict__ c_vals,
     const int *__restrict__ a_nnz_ptr, const VT *__restrict__ a_vals, const uint32_t *__restrict__ a_rec,
