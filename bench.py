@@ -419,7 +419,8 @@ def main(argv=None):
                 sha = tj.get("__meta__", {}).get("kernels_sha")
                 if sha == kernels_sha():             # a table taken from other kernel sources says nothing about this run
                     traffic = tj.get(dom, {}).get("hbm_bytes_per_launch")
-                    traffic_source = f"profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes; kernels sha {sha})"
+                    traffic_source = (f"profiles/pmc_traffic.json ({tj.get('__meta__', {}).get('source', 'rocprofv3 --pmc, separate passes')}; "
+                                      f"kernels sha {sha})")
                 else:
                     traffic_source = f"none: profiles/pmc_traffic.json was taken from kernels sha {sha}, this run is {kernels_sha()}"
             except Exception:
